@@ -1,0 +1,90 @@
+"""ctypes binding of libvvc_mi355.so (the C ABI declared in include/vvc_mi355.h).
+
+The library is the product: there is no CPU fallback.  Loading fails loudly when the in-tree
+shared object has not been built (``python -c 'import __graft_entry__ as g; g.build()'``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvvc_mi355.so")
+
+_C = {
+    "i": ctypes.c_int,
+    "p": ctypes.c_void_p,
+    "q": ctypes.c_ssize_t,     # ptrdiff_t / intptr_t
+    "z": ctypes.c_size_t,
+    "v": None,
+}
+
+# name (without the vvc355_/orc_ prefix) -> (return code, argument codes).
+# The CPU oracle used by the tests exports the same slot signatures under the orc_ prefix, so the
+# table is shared between the two libraries (tests/conftest.py).
+SLOT_SIGNATURES = {
+    # ---- ALF
+    "alf_filter_luma":          ("v", "ipqpqiippi"),
+    "alf_filter_chroma":        ("v", "ipqpqiippi"),
+    "alf_filter_cc":            ("v", "ipqpqiiiipi"),
+    "alf_classify":             ("v", "ipppqiiip"),
+    "alf_recon_coeff_and_clip": ("v", "ippppippp"),
+}
+
+RUNTIME_SIGNATURES = {
+    "device_count":   ("i", ""),
+    "set_device":     ("v", "i"),
+    "malloc":         ("p", "z"),
+    "free":           ("v", "p"),
+    "upload":         ("v", "ppz"),
+    "download":       ("v", "ppz"),
+    "stream_create":  ("p", ""),
+    "stream_destroy": ("v", "p"),
+    "stream_sync":    ("v", "p"),
+    "version":        ("p", ""),
+}
+
+BATCH_SIGNATURES = {
+    "alf_luma_batch":   ("v", "piipi"),
+    "alf_chroma_batch": ("v", "pipi"),
+    "alf_cc_batch":     ("v", "pipi"),
+}
+
+
+def bind(lib: ctypes.CDLL, prefix: str, table: dict) -> None:
+    """Attach restype/argtypes for every entry of `table` found under `prefix` in `lib`."""
+    for name, (ret, args) in table.items():
+        fn = getattr(lib, prefix + name)        # AttributeError = missing symbol: loud on purpose
+        fn.restype = _C[ret]
+        fn.argtypes = [_C[a] for a in args]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libvvc_mi355.so (once) and bind every declared entry point."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (__graft_entry__.build()); "
+                "this package has no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        bind(lib, "vvc355_", SLOT_SIGNATURES)
+        bind(lib, "vvc355_", RUNTIME_SIGNATURES)
+        bind(lib, "vvc355_", BATCH_SIGNATURES)
+        _lib = lib
+    return _lib
+
+
+class AlfJob(ctypes.Structure):
+    """Mirror of vvc355_alf_job (include/vvc_mi355.h)."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("src", ctypes.c_uint64), ("coeff", ctypes.c_uint64),
+        ("clip", ctypes.c_uint64), ("class_to_filt", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("src_stride", ctypes.c_int32),
+        ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("vb_pos", ctypes.c_int16),
+        ("ext_l", ctypes.c_int8), ("ext_r", ctypes.c_int8), ("ext_t", ctypes.c_int8), ("ext_b", ctypes.c_int8),
+        ("hs", ctypes.c_int8), ("vs", ctypes.c_int8), ("pad_", ctypes.c_int8 * 4),
+    ]

@@ -1,0 +1,504 @@
+// ALF (adaptive loop filter) kernels for gfx950: luma 7x7 diamond (per-4x4 coefficient sets, or fused with the
+// block classification + coefficient gather), chroma 5x5 diamond, cross-component ALF, and the stand-alone
+// classify / recon_coeff_and_clip slots.
+//
+// Reference behaviour: libavcodec/vvc/vvc_filter_template.c:38-408 (alf_clip :38, alf_filter_luma :43,
+// alf_filter_chroma :137, alf_filter_cc :223, alf_get_idx :270, alf_classify :299, alf_recon_coeff_and_clip :383)
+// and the caller's padding rules libavcodec/vvc/vvc_filter.c:1105-1137 (alf_prepare_buffer = clamp-to-edge).
+//
+// Layout: one workgroup (256 lanes) owns a 128-wide x 32-tall strip of one job rectangle.  The strip plus a
+// 3-sample apron is staged through LDS as uint16 with 16-byte global loads; every lane then owns ONE 4x4 block
+// (the unit that shares a coefficient set), pulls its 10x12-sample window into registers with aligned
+// ds_read_b64, and classifies + filters from registers.  Rows next to the virtual boundary take a slower LDS path.
+#include "common.hpp"
+#include "runtime.hpp"
+#include "../../include/vvc_mi355.h"
+
+namespace vvc355 {
+
+static constexpr int kStripH  = 32;            // rows per workgroup
+static constexpr int kTileW   = 144;           // LDS row: columns -8 .. 135  (index = column + 8)
+static constexpr int kTileH   = kStripH + 6;   // rows -3 .. 34
+static constexpr int kColOff  = 8;
+
+__device__ static const uint8_t kAlfPerm[4][12] = {       // vvc_filter_template.c:387-392
+    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 },
+    { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6 },
+    { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11 },
+    { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6 },
+};
+__device__ static const uint8_t kAlfVarTab[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+// luma diamond taps (dy, dx), paired with (-dy, -dx): vvc_filter_template.c:102-113
+__device__ static const int8_t kLumaTap[12][2] = {
+    { 3, 0 }, { 2, 1 }, { 2, 0 }, { 2, -1 }, { 1, 2 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 1, -2 }, { 0, 3 }, { 0, 2 }, { 0, 1 },
+};
+__device__ static const int8_t kChromaTap[6][2] = { { 2, 0 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 0, 2 }, { 0, 1 } };
+
+// rows between row y and the virtual boundary on y's own side (0 = adjacent): taps fold to min(k, dist)
+__device__ __forceinline__ int vb_dist(int y, int vb_pos) { return y < vb_pos ? vb_pos - 1 - y : y - vb_pos; }
+
+// ---------------------------------------------------------------------------------------------- tile staging
+
+// Stage rows [y_base-3, y_base+rows+3) x columns [-8, 136) of the job's source rectangle into LDS as uint16,
+// replicating at the readable-apron limits (ext_*), which is what the reference's alf_prepare_buffer produces.
+template <int BD>
+__device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc355_alf_job &job, int y_base, int rows, int apron)
+{
+    using px_t = typename Px<BD>::type;
+    const uint8_t *src = (const uint8_t *)job.src;
+    const int w = job.w, h = job.h;
+    const int x_min = -min((int)job.ext_l, apron), x_max = w - 1 + min((int)job.ext_r, apron);
+    const int y_min = -min((int)job.ext_t, apron), y_max = h - 1 + min((int)job.ext_b, apron);
+    const int nchunk = kTileW / 8;
+    const bool aligned = (((uintptr_t)src | (uintptr_t)job.src_stride) & (sizeof(px_t) * 8 - 1)) == 0;
+
+    for (int i = threadIdx.x; i < (rows + 6) * nchunk; i += blockDim.x) {
+        const int r = i / nchunk, k = i - r * nchunk;
+        const int y = clip3(y_base + r - 3, y_min, y_max);
+        const int c0 = k * 8 - kColOff;
+        const px_t *row = (const px_t *)(src + (ptrdiff_t)y * job.src_stride);
+        uint16_t v[8];
+        if (aligned && c0 >= 0 && c0 + 8 <= w) {
+            if (BD > 8) {
+                const uint4 q = *(const uint4 *)(row + c0);
+                *(uint4 *)&tile[r][k * 8] = q;
+                continue;
+            } else {
+                const uint2 q = *(const uint2 *)(row + c0);
+                const uint32_t d[2] = { q.x, q.y };
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v[j] = (d[j >> 2] >> ((j & 3) * 8)) & 0xff;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                v[j] = row[clip3(c0 + j, x_min, x_max)];
+        }
+        uint4 q;
+        q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16); q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
+        *(uint4 *)&tile[r][k * 8] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- classification
+
+// vvc_filter_template.c:270 — direction sums {V,H,D0,D1} -> class 0..24 and transpose 0..3
+template <int BD>
+__device__ __forceinline__ void block_class(const int sum[4], int ac, int &cls, int &tr)
+{
+    const int v = sum[0], h = sum[1], d0 = sum[2], d1 = sum[3];
+    const int dir_hv = v <= h, dir_d = d0 <= d1;
+    const int hv_hi = max(v, h), hv_lo = min(v, h), d_hi = max(d0, d1), d_lo = min(d0, d1);
+    const int main_hv = (uint64_t)(uint32_t)d_hi * (uint32_t)hv_lo <= (uint64_t)(uint32_t)hv_hi * (uint32_t)d_lo;
+    const int hi = main_hv ? hv_hi : d_hi, lo = main_hv ? hv_lo : d_lo;
+    cls = kAlfVarTab[clip3(((h + v) * ac) >> (BD - 1), 0, 15)];
+    if (hi * 2 > 9 * lo)
+        cls += ((main_hv << 1) + 2) * 5;
+    else if (hi > 2 * lo)
+        cls += ((main_hv << 1) + 1) * 5;
+    tr = dir_d * 2 + dir_hv;
+}
+
+// register window of one 4x4 block: rows y-3 .. y+6, columns x-4 .. x+7, two samples per dword
+struct Win {
+    uint32_t d[10][6];
+    __device__ __forceinline__ int at(int r, int c) const { return (d[r][c >> 1] >> ((c & 1) * 16)) & 0xffff; }
+};
+
+// Classification of the block at CTB row yb from its window (vvc_filter_template.c:299-381 restricted to one block).
+template <int BD>
+__device__ __forceinline__ void classify_win(const Win &w, int yb, int vb_pos, int &cls, int &tr)
+{
+    int first = 0, last = 4, ac = 2;
+    if (yb + 4 == vb_pos) { last = 3; ac = 3; }
+    else if (yb == vb_pos) { first = 1; ac = 3; }
+    int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // gradient row i covers loop row yy = yb + 2i of the reference: sample A on window row 1+2i, B on 2+2i
+        const int yy = yb + 2 * i;
+        const bool fold_dn = yy == vb_pos;        // B's lower neighbour row replaced by B's row
+        const bool fold_up = yy == vb_pos + 2;    // A's upper neighbour row replaced by A's row
+        const int ra = 1 + 2 * i, rb = ra + 1;
+        int g[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ca = 2 + 2 * j, cb = ca + 1;
+            const int a2 = w.at(ra, ca) << 1, b2 = w.at(rb, cb) << 1;
+#define UPA(c) (fold_up ? w.at(ra, c) : w.at(ra - 1, c))
+#define DNB(c) (fold_dn ? w.at(rb, c) : w.at(rb + 1, c))
+            g[0] += abs(a2 - UPA(ca) - w.at(rb, ca)) + abs(b2 - w.at(ra, cb) - DNB(cb));
+            g[1] += abs(a2 - w.at(ra, ca - 1) - w.at(ra, ca + 1)) + abs(b2 - w.at(rb, cb - 1) - w.at(rb, cb + 1));
+            g[2] += abs(a2 - UPA(ca - 1) - w.at(rb, ca + 1)) + abs(b2 - w.at(ra, cb - 1) - DNB(cb + 1));
+            g[3] += abs(a2 - UPA(ca + 1) - w.at(rb, ca - 1)) + abs(b2 - w.at(ra, cb + 1) - DNB(cb - 1));
+#undef UPA
+#undef DNB
+        }
+        if (i >= first && i < last) {
+            sum[0] += g[0]; sum[1] += g[1]; sum[2] += g[2]; sum[3] += g[3];
+        }
+    }
+    block_class<BD>(sum, ac, cls, tr);
+}
+
+// ---------------------------------------------------------------------------------------------- luma kernel
+
+// MODE 0: per-4x4 coefficient/clip arrays (the reference's alf.filter[LUMA] slot).
+// MODE 1: fused classify -> coefficient gather -> filter (the three slots the caller chains, vvc_filter.c:1139-1186).
+// MODE 2: classify only (alf.classify slot): writes class_idx / transpose_idx ints.
+template <int BD, int MODE>
+__global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__restrict__ jobs)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
+    const vvc355_alf_job job = jobs[blockIdx.x >> 2];
+    const int y_base = (blockIdx.x & 3) * kStripH;
+    if (y_base >= job.h)
+        return;
+    const int rows = min(kStripH, job.h - y_base);
+    stage_tile<BD>(tile, job, y_base, rows, 3);
+    __syncthreads();
+
+    const int bx = threadIdx.x & 31, by = threadIdx.x >> 5;
+    const int x = bx * 4, yl = by * 4, yb = y_base + yl;
+    if (x >= job.w || yl >= rows)
+        return;
+
+    Win win;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint2 *p = (const uint2 *)&tile[yl + r][x + kColOff - 4];
+        const uint2 a = p[0], b = p[1], c = p[2];
+        win.d[r][0] = a.x; win.d[r][1] = a.y; win.d[r][2] = b.x; win.d[r][3] = b.y; win.d[r][4] = c.x; win.d[r][5] = c.y;
+    }
+
+    const int vb_pos = job.vb_pos;
+    const int blk = (yb >> 2) * (job.w >> 2) + bx;
+    int f[12], c[12];
+    if (MODE == 0) {
+        const int16_t *fp = (const int16_t *)job.coeff + blk * 12, *cp = (const int16_t *)job.clip + blk * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { f[k] = fp[k]; c[k] = cp[k]; }
+    } else {
+        int cls, tr;
+        classify_win<BD>(win, yb, vb_pos, cls, tr);
+        if (MODE == 2) {
+            ((int *)job.coeff)[blk] = cls;
+            ((int *)job.clip)[blk] = tr;
+            return;
+        }
+        // alf_recon_coeff_and_clip (:383) for this block
+        const int16_t *cs = (const int16_t *)job.coeff + ((const uint8_t *)job.class_to_filt)[cls] * 12;
+        const uint8_t *ci = (const uint8_t *)job.clip + cls * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int idx = kAlfPerm[tr][k];
+            const int q = ci[idx];
+            f[k] = cs[idx];
+            c[k] = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
+        }
+    }
+
+    uint8_t *dst = (uint8_t *)job.dst;
+    // rows of this block closer than 3 to the virtual boundary fold their taps: generic LDS path
+    const bool near_vb = vb_dist(yb, vb_pos) < 3 || vb_dist(yb + 3, vb_pos) < 3 || (yb < vb_pos && yb + 3 >= vb_pos);
+    if (!near_vb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int out[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r0 = 3 + i, c0 = 4 + j;
+                const int cur = win.at(r0, c0);
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const int dy = kLumaTap[k][0], dx = kLumaTap[k][1];
+                    const int a = win.at(r0 + dy, c0 + dx), b = win.at(r0 - dy, c0 - dx);
+                    sum += f[k] * (clip3(a - cur, -c[k], c[k]) + clip3(b - cur, -c[k], c[k]));
+                }
+                out[j] = clip_px<BD>(((sum + 64) >> 7) + cur);
+            }
+            uint8_t *d = dst + (ptrdiff_t)(yb + i) * job.dst_stride;
+            if (BD > 8)
+                *(uint2 *)(d + x * 2) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+            else
+                *(uint32_t *)(d + x) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+        }
+    } else {
+        for (int i = 0; i < 4; i++) {
+            const int y = yb + i, dist = vb_dist(y, vb_pos);
+            const int tr0 = yl + i + 3;
+            for (int j = 0; j < 4; j++) {
+                const int tc0 = x + j + kColOff;
+                const int cur = tile[tr0][tc0];
+                int sum = 0;
+                for (int k = 0; k < 12; k++) {
+                    const int dy = min((int)kLumaTap[k][0], dist), dx = kLumaTap[k][1];
+                    const int a = tile[tr0 + dy][tc0 + dx], b = tile[tr0 - dy][tc0 - dx];
+                    sum += f[k] * (clip3(a - cur, -c[k], c[k]) + clip3(b - cur, -c[k], c[k]));
+                }
+                sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
+                st_px<BD>(dst + (ptrdiff_t)y * job.dst_stride, x + j, clip_px<BD>(sum + cur));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- chroma kernel
+
+// alf.filter[CHROMA] (:137): one 6-tap set per rectangle; rectangle up to 128x128 (4:4:4), usually 64x64.
+template <int BD>
+__global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *__restrict__ jobs)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
+    const vvc355_alf_job job = jobs[blockIdx.x >> 2];
+    const int y_base = (blockIdx.x & 3) * kStripH;
+    if (y_base >= job.h)
+        return;
+    const int rows = min(kStripH, job.h - y_base);
+    stage_tile<BD>(tile, job, y_base, rows, 2);
+    __syncthreads();
+
+    int f[6], c[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { f[k] = ((const int16_t *)job.coeff)[k]; c[k] = ((const int16_t *)job.clip)[k]; }
+    uint8_t *dst = (uint8_t *)job.dst;
+    const int vb_pos = job.vb_pos;
+    // lane -> 4 consecutive samples of one row
+    for (int i = threadIdx.x; i < rows * 32; i += blockDim.x) {
+        const int yl = i >> 5, x = (i & 31) * 4;
+        if (x >= job.w)
+            continue;
+        const int y = y_base + yl, dist = vb_dist(y, vb_pos), tr0 = yl + 3;
+        int out[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int tc0 = x + j + kColOff;
+            const int cur = tile[tr0][tc0];
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int dy = min((int)kChromaTap[k][0], dist), dx = kChromaTap[k][1];
+                const int a = tile[tr0 + dy][tc0 + dx], b = tile[tr0 - dy][tc0 - dx];
+                sum += f[k] * (clip3(a - cur, -c[k], c[k]) + clip3(b - cur, -c[k], c[k]));
+            }
+            sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
+            out[j] = clip_px<BD>(sum + cur);
+        }
+        uint8_t *d = dst + (ptrdiff_t)y * job.dst_stride;
+        if (BD > 8)
+            *(uint2 *)(d + x * 2) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+        else
+            *(uint32_t *)(d + x) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- CC-ALF kernel
+
+// alf.filter_cc (:223): dst = chroma rectangle (w x h), src = co-located luma; job.coeff = int16[7];
+// job.ext_* unused (the 1-sample luma neighbourhood is read in place, as the reference does from its padded copy).
+template <int BD>
+__global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__restrict__ jobs)
+{
+    const vvc355_alf_job job = jobs[blockIdx.y];
+    const int hs = job.hs, vs = job.vs, vb_pos = job.vb_pos;
+    const uint8_t *luma = (const uint8_t *)job.src;
+    const ptrdiff_t ls = job.src_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    int f[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) f[k] = ((const int16_t *)job.coeff)[k];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
+        const int y = i / job.w, x = i - y * job.w;
+        const int ly = y << vs;
+        if (!vs && (ly == vb_pos || ly == vb_pos + 1))
+            continue;
+        int up = -1, dn = 1, dn2 = 2;
+        if (ly == vb_pos - 2 || ly == vb_pos + 1) dn2 = 1;
+        else if (ly == vb_pos - 1 || ly == vb_pos) up = dn = dn2 = 0;
+        const ptrdiff_t o = (ptrdiff_t)ly * ls + (x << hs);
+        const int c = ld_px<BD>(luma, o);
+        int sum = 0;
+        sum += f[0] * (ld_px<BD>(luma, o + up * ls) - c);
+        sum += f[1] * (ld_px<BD>(luma, o - 1) - c);
+        sum += f[2] * (ld_px<BD>(luma, o + 1) - c);
+        sum += f[3] * (ld_px<BD>(luma, o + dn * ls - 1) - c);
+        sum += f[4] * (ld_px<BD>(luma, o + dn * ls) - c);
+        sum += f[5] * (ld_px<BD>(luma, o + dn * ls + 1) - c);
+        sum += f[6] * (ld_px<BD>(luma, o + dn2 * ls) - c);
+        sum = clip3((sum + 64) >> 7, -(1 << (BD - 1)), (1 << (BD - 1)) - 1);
+        uint8_t *d = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
+        st_px<BD>(d, x, clip_px<BD>(sum + ld_px<BD>(d, x)));
+    }
+}
+
+// alf.recon_coeff_and_clip (:383) as its own slot
+template <int BD>
+__global__ void alf_recon_kernel(int16_t *coeff, int16_t *clip, const int *class_idx, const int *transpose_idx, int size,
+                                 const int16_t *coeff_set, const uint8_t *clip_idx_set, const uint8_t *class_to_filt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size * 12)
+        return;
+    const int b = i / 12, j = i - b * 12;
+    const int cls = class_idx[b], idx = kAlfPerm[transpose_idx[b]][j];
+    const int q = clip_idx_set[cls * 12 + idx];
+    coeff[i] = coeff_set[class_to_filt[cls] * 12 + idx];
+    clip[i] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+
+static void launch_luma(int bd, int mode, const vvc355_alf_job *jobs, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    const dim3 grid(n * 4), block(256);
+    VVC355_BD_DISPATCH(bd, {
+        if (mode == 0)      hipLaunchKernelGGL((alf_luma_kernel<BD, 0>), grid, block, 0, st, jobs);
+        else if (mode == 1) hipLaunchKernelGGL((alf_luma_kernel<BD, 1>), grid, block, 0, st, jobs);
+        else                hipLaunchKernelGGL((alf_luma_kernel<BD, 2>), grid, block, 0, st, jobs);
+    });
+    HIP_CHECK(hipGetLastError());
+}
+
+static void launch_chroma(int bd, const vvc355_alf_job *jobs, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_chroma_kernel<BD>), dim3(n * 4), dim3(256), 0, st, jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+static void launch_cc(int bd, const vvc355_alf_job *jobs, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_cc_kernel<BD>), dim3(4, n), dim3(256), 0, st, jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+static void check_luma_dims(int w, int h)
+{
+    if (w <= 0 || h <= 0 || w > 128 || h > 128 || (w & 3) || (h & 3)) {
+        fprintf(stderr, "vvc_mi355: ALF rectangle %dx%d outside the slot's domain (multiples of 4, <= 128)\n", w, h);
+        abort();
+    }
+}
+
+} // namespace vvc355
+
+using namespace vvc355;
+
+// =============================================================================================== C ABI
+
+extern "C" {
+
+// ---- batched (device-resident) entries
+void vvc355_alf_luma_batch(void *stream, int bd, int fused, const vvc355_alf_job *jobs_dev, int n_jobs)
+{
+    launch_luma(bd, fused ? 1 : 0, jobs_dev, n_jobs, (hipStream_t)stream);
+}
+void vvc355_alf_chroma_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, int n_jobs)
+{
+    launch_chroma(bd, jobs_dev, n_jobs, (hipStream_t)stream);
+}
+void vvc355_alf_cc_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, int n_jobs)
+{
+    launch_cc(bd, jobs_dev, n_jobs, (hipStream_t)stream);
+}
+
+// ---- synchronous per-slot entries (host pointers; reference signatures + leading bd)
+void vvc355_alf_filter_luma(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+                            int width, int height, const int16_t *filter, const int16_t *clip, int vb_pos)
+{
+    check_luma_dims(width, height);
+    const int px = bd > 8 ? 2 : 1, nblk = (width >> 2) * (height >> 2);
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, -3 * px, (width + 3) * px, -3, height + 3, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, false, true);
+    vvc355_alf_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev;
+    job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.coeff = (uint64_t)call.linear(filter, (size_t)nblk * 24, true, false);
+    job.clip = (uint64_t)call.linear(clip, (size_t)nblk * 24, true, false);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.vb_pos = (int16_t)vb_pos;
+    job.ext_l = job.ext_r = job.ext_t = job.ext_b = 3;
+    launch_luma(bd, 0, call.upload(&job, 1), 1, call.stream());
+}
+
+void vvc355_alf_filter_chroma(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+                              int width, int height, const int16_t *filter, const int16_t *clip, int vb_pos)
+{
+    check_luma_dims(width, height);
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, -2 * px, (width + 2) * px, -2, height + 2, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, false, true);
+    vvc355_alf_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev;
+    job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.coeff = (uint64_t)call.linear(filter, 12, true, false);
+    job.clip = (uint64_t)call.linear(clip, 12, true, false);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.vb_pos = (int16_t)vb_pos;
+    job.ext_l = job.ext_r = job.ext_t = job.ext_b = 2;
+    launch_chroma(bd, call.upload(&job, 1), 1, call.stream());
+}
+
+void vvc355_alf_filter_cc(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *luma, ptrdiff_t luma_stride,
+                          int width, int height, int hs, int vs, const int16_t *filter, int vb_pos)
+{
+    if (width <= 0 || height <= 0)
+        return;
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    const Staged s = call.rect(luma, luma_stride, -px, ((width << hs) + 1) * px, -1, (height << vs) + 2, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, true, true);
+    vvc355_alf_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev;
+    job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.coeff = (uint64_t)call.linear(filter, 14, true, false);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.vb_pos = (int16_t)vb_pos;
+    job.hs = (int8_t)hs; job.vs = (int8_t)vs;
+    launch_cc(bd, call.upload(&job, 1), 1, call.stream());
+}
+
+void vvc355_alf_classify(int bd, int *class_idx, int *transpose_idx, const uint8_t *src, ptrdiff_t src_stride,
+                         int width, int height, int vb_pos, int *gradient_tmp)
+{
+    (void)gradient_tmp;      // the reference's scratch plane; the kernel keeps gradients in registers
+    check_luma_dims(width, height);
+    const int px = bd > 8 ? 2 : 1, nblk = (width >> 2) * (height >> 2);
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, -3 * px, (width + 3) * px, -3, height + 3, true, false);
+    vvc355_alf_job job = {};
+    job.src = (uint64_t)s.dev; job.src_stride = (int32_t)s.pitch;
+    job.coeff = (uint64_t)call.linear(class_idx, (size_t)nblk * 4, false, true);
+    job.clip = (uint64_t)call.linear(transpose_idx, (size_t)nblk * 4, false, true);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.vb_pos = (int16_t)vb_pos;
+    job.ext_l = job.ext_r = job.ext_t = job.ext_b = 3;
+    launch_luma(bd, 2, call.upload(&job, 1), 1, call.stream());
+}
+
+void vvc355_alf_recon_coeff_and_clip(int bd, int16_t *coeff, int16_t *clip, const int *class_idx, const int *transpose_idx,
+                                     int size, const int16_t *coeff_set, const uint8_t *clip_idx_set,
+                                     const uint8_t *class_to_filt)
+{
+    if (size <= 0)
+        return;
+    // the slot does not say how many filters coeff_set holds; the class map (host memory) bounds what is read
+    int n_filters = 0;
+    for (int i = 0; i < 25; i++)
+        n_filters = class_to_filt[i] + 1 > n_filters ? class_to_filt[i] + 1 : n_filters;
+    SlotCall call;
+    int16_t *d_coeff = (int16_t *)call.linear(coeff, (size_t)size * 24, false, true);
+    int16_t *d_clip = (int16_t *)call.linear(clip, (size_t)size * 24, false, true);
+    const int *d_cls = (const int *)call.linear(class_idx, (size_t)size * 4, true, false);
+    const int *d_tr = (const int *)call.linear(transpose_idx, (size_t)size * 4, true, false);
+    const int16_t *d_set = (const int16_t *)call.linear(coeff_set, (size_t)n_filters * 24, true, false);
+    const uint8_t *d_ci = (const uint8_t *)call.linear(clip_idx_set, 25 * 12, true, false);
+    const uint8_t *d_map = (const uint8_t *)call.linear(class_to_filt, 25, true, false);
+    const int n = size * 12;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_recon_kernel<BD>), dim3((n + 255) / 256), dim3(256), 0, call.stream(),
+                                              d_coeff, d_clip, d_cls, d_tr, size, d_set, d_ci, d_map));
+    HIP_CHECK(hipGetLastError());
+}
+
+} // extern "C"

@@ -1,0 +1,82 @@
+#include "runtime.hpp"
+
+namespace vvc355 {
+
+static constexpr size_t kArenaBytes = 48u << 20;   // far above any single slot call (largest: 128x135 int16 planes)
+
+ThreadCtx::ThreadCtx()
+{
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipMalloc((void **)&dev, kArenaBytes));
+    cap = kArenaBytes;
+}
+
+ThreadCtx::~ThreadCtx()
+{
+    // Process teardown may already have destroyed the HIP runtime; ignore errors here.
+    if (dev) (void)hipFree(dev);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+ThreadCtx &thread_ctx()
+{
+    static thread_local ThreadCtx ctx;
+    return ctx;
+}
+
+SlotCall::SlotCall() : ctx_(thread_ctx()) {}
+
+SlotCall::~SlotCall()
+{
+    for (const Out &o : outs_)
+        HIP_CHECK(hipMemcpy2DAsync(o.host, o.hstride, o.dev, o.dpitch, o.width, o.rows, hipMemcpyDeviceToHost, ctx_.stream));
+    HIP_CHECK(hipStreamSynchronize(ctx_.stream));
+}
+
+uint8_t *SlotCall::bump(size_t bytes)
+{
+    const size_t at = (used_ + 255) & ~(size_t)255;
+    if (at + bytes > ctx_.cap) {
+        fprintf(stderr, "vvc_mi355: slot staging arena exhausted (%zu + %zu > %zu)\n", at, bytes, ctx_.cap);
+        abort();
+    }
+    used_ = at + bytes;
+    return ctx_.dev + at;
+}
+
+Staged SlotCall::rect(const void *host, ptrdiff_t stride, ptrdiff_t x_lo, ptrdiff_t x_hi, int y_lo, int y_hi,
+                      bool upload, bool download)
+{
+    Staged s;
+    const size_t width = (size_t)(x_hi - x_lo);
+    const int rows = y_hi - y_lo;
+    // the caller's origin lands 64-byte aligned on the device, with a 64-byte-multiple pitch, so the
+    // kernels' vector paths apply whatever the host alignment was
+    const size_t lead = ((size_t)(-x_lo) + 63) & ~(size_t)63;       // x_lo <= 0 for every caller
+    s.pitch = (ptrdiff_t)((lead + (size_t)x_hi + 63) & ~(size_t)63);
+    uint8_t *blk = bump((size_t)s.pitch * (size_t)rows + 64);
+    s.dev = blk + lead - (ptrdiff_t)y_lo * s.pitch;
+    uint8_t *h0 = (uint8_t *)const_cast<void *>(host) + (ptrdiff_t)y_lo * stride + x_lo;
+    uint8_t *d0 = s.dev + (ptrdiff_t)y_lo * s.pitch + x_lo;
+    if (width == 0 || rows <= 0)
+        return s;
+    if (upload)
+        HIP_CHECK(hipMemcpy2DAsync(d0, s.pitch, h0, stride, width, rows, hipMemcpyHostToDevice, ctx_.stream));
+    if (download)
+        outs_.push_back({ h0, stride, d0, s.pitch, width, rows });
+    return s;
+}
+
+void *SlotCall::linear(const void *host, size_t bytes, bool upload, bool download)
+{
+    uint8_t *d = bump(bytes ? bytes : 1);
+    if (bytes && upload)
+        HIP_CHECK(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx_.stream));
+    if (bytes && download)
+        outs_.push_back({ const_cast<void *>(host), (ptrdiff_t)bytes, d, (ptrdiff_t)bytes, bytes, 1 });
+    return d;
+}
+
+void *SlotCall::scratch(size_t bytes) { return bump(bytes ? bytes : 1); }
+
+} // namespace vvc355

@@ -1,0 +1,350 @@
+/*
+ * oracle/orc_inter.c — CPU restatement of the inter-prediction DSP slots.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see orc_common.h).
+ *
+ * Follows, by reading:
+ *   libavcodec/h26x/h2656_inter_template.c  (put/put_uni/put_uni_w x {pixels,h,v,hv}, luma :29-334, chroma :336-577)
+ *   libavcodec/vvc/vvc_inter_template.c     (avg :25, w_avg :42, ciip :60, gpm :78, bdof/prof :101-317, dmvr :324-413)
+ *   libavcodec/vvc/vvcdsp.c                 (pad_int16 :29, vvc_sad :49)
+ */
+#include "vvc_oracle.h"
+#include "orc_common.h"
+
+/* ------------------------------------------------------------------ separable DCTIF (8-tap luma / 4-tap chroma) */
+
+/* Σ f[k] * px[o + (k - lead) * step]; lead = 3 (luma) or 1 (chroma): h2656_inter_template.c:87,:336 */
+ORC_INLINE int fir_pixels(const uint8_t *src, ptrdiff_t o, ptrdiff_t step, const int8_t *f, int ntap, int wide)
+{
+    const int lead = ntap == 8 ? 3 : 1;
+    int acc = 0;
+    for (int k = 0; k < ntap; k++)
+        acc += f[k] * orc_ld(src, o + (k - lead) * step, wide);
+    return acc;
+}
+
+ORC_INLINE int fir_i16(const int16_t *t, ptrdiff_t o, ptrdiff_t step, const int8_t *f, int ntap)
+{
+    const int lead = ntap == 8 ? 3 : 1;
+    int acc = 0;
+    for (int k = 0; k < ntap; k++)
+        acc += f[k] * t[o + (k - lead) * step];
+    return acc;
+}
+
+enum { MC_PUT, MC_UNI, MC_UNI_W };
+
+/*
+ * All twelve (kind x frac) variants of one component share this body.  `val` is the 14-bit-scaled
+ * intermediate; what happens to it afterwards depends on `kind`:
+ *   put      : stored to int16 (row stride 128)                     — :29,:97,:112,:127
+ *   put_uni  : clip_px((val + 2^(13-bd)) >> (14-bd))                — :154-245 (integer position = plain copy :44)
+ *   put_uni_w: clip_px(((val*wx + 2^(shift-1)) >> shift) + ox*2^(bd-8)), shift = denom + 14 - bd — :60,:247-334
+ */
+ORC_INLINE void mc_body(const int bd, const int ntap, const int kind, const int vfrac, const int hfrac,
+    int16_t *dst16, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+    int h, int denom, int wx, int ox_in, const int8_t *hf, const int8_t *vf, int w)
+{
+    const int wide = bd > 8;
+    const int lead = ntap == 8 ? 3 : 1;
+    const ptrdiff_t ss = src_stride >> wide;
+    const int sh_uni = 14 - bd, off_uni = 1 << (sh_uni - 1);
+    const int sh_w = denom + 14 - bd, off_w = 1 << (sh_w - 1);
+    const int ox = ox_in * (1 << (bd - 8));
+    int16_t tmp[(ORC_PB + 7) * ORC_PB];
+
+    if (vfrac && hfrac) {
+        /* horizontal pass over h + ntap - 1 rows into an int16 plane of row stride 128 (:135-141) */
+        for (int y = 0; y < h + ntap - 1; y++)
+            for (int x = 0; x < w; x++)
+                tmp[y * ORC_PB + x] = (int16_t)(fir_pixels(src, (ptrdiff_t)(y - lead) * ss + x, 1, hf, ntap, wide) >> (bd - 8));
+    }
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const ptrdiff_t o = (ptrdiff_t)y * ss + x;
+            int val;
+            if (vfrac && hfrac)
+                val = fir_i16(tmp, (ptrdiff_t)(y + lead) * ORC_PB + x, ORC_PB, vf, ntap) >> 6;
+            else if (hfrac)
+                val = fir_pixels(src, o, 1, hf, ntap, wide) >> (bd - 8);
+            else if (vfrac)
+                val = fir_pixels(src, o, ss, vf, ntap, wide) >> (bd - 8);
+            else
+                val = orc_ld(src, o, wide) << (14 - bd);
+            if (kind == MC_PUT)
+                dst16[y * ORC_PB + x] = (int16_t)val;
+            else if (kind == MC_UNI)
+                orc_st(dst + y * dst_stride, x, (vfrac || hfrac) ? orc_clip_px((val + off_uni) >> sh_uni, bd) : orc_ld(src, o, wide), wide);
+            else
+                orc_st(dst + y * dst_stride, x, orc_clip_px(((val * wx + off_w) >> sh_w) + ox, bd), wide);
+        }
+    }
+}
+
+#define MC_CALL(BD) mc_body(BD, chroma ? 4 : 8, kind, vfrac, hfrac, dst16, dst, dst_stride, src, src_stride, height, denom, wx, ox, hf, vf, width)
+static void mc_dispatch(int bd, int chroma, int kind, int vfrac, int hfrac, int16_t *dst16, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, int denom, int wx, int ox, const int8_t *hf, const int8_t *vf, int width)
+{
+    ORC_BD_SWITCH(bd, MC_CALL(8), MC_CALL(10), MC_CALL(12));
+}
+
+ORC_API void orc_put(int bd, int chroma, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride,
+    int height, const int8_t *hf, const int8_t *vf, int width)
+{
+    mc_dispatch(bd, chroma, MC_PUT, vfrac, hfrac, dst, NULL, 0, src, src_stride, height, 0, 0, 0, hf, vf, width);
+}
+
+ORC_API void orc_put_uni(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, const int8_t *hf, const int8_t *vf, int width)
+{
+    mc_dispatch(bd, chroma, MC_UNI, vfrac, hfrac, NULL, dst, dst_stride, src, src_stride, height, 0, 0, 0, hf, vf, width);
+}
+
+ORC_API void orc_put_uni_w(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, int denom, int wx, int ox,
+    const int8_t *hf, const int8_t *vf, int width)
+{
+    mc_dispatch(bd, chroma, MC_UNI_W, vfrac, hfrac, NULL, dst, dst_stride, src, src_stride, height, denom, wx, ox, hf, vf, width);
+}
+
+/* ------------------------------------------------------------------ bi-prediction blends */
+
+/* vvc_inter_template.c:25 */
+ORC_API void orc_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height)
+{
+    const int wide = bd > 8, shift = orc_max(3, 15 - bd), off = 1 << (shift - 1);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            orc_st(dst + y * dst_stride, x, orc_clip_px((src0[y * ORC_PB + x] + src1[y * ORC_PB + x] + off) >> shift, bd), wide);
+}
+
+/* vvc_inter_template.c:42 */
+ORC_API void orc_w_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height,
+    int denom, int w0, int w1, int o0, int o1)
+{
+    const int wide = bd > 8, shift = denom + orc_max(3, 15 - bd);
+    const int off = (((o0 + o1) << (bd - 8)) + 1) << (shift - 1);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            orc_st(dst + y * dst_stride, x,
+                   orc_clip_px((src0[y * ORC_PB + x] * w0 + src1[y * ORC_PB + x] * w1 + off) >> shift, bd), wide);
+}
+
+/* vvc_inter_template.c:60 — dst holds the intra prediction; no clip, result truncated to the pixel type */
+ORC_API void orc_put_ciip(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const uint8_t *inter, ptrdiff_t inter_stride, int intra_weight)
+{
+    const int wide = bd > 8, inter_weight = 4 - intra_weight;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            uint8_t *d = dst + y * dst_stride;
+            orc_st(d, x, (orc_ld(d, x, wide) * intra_weight + orc_ld(inter + y * inter_stride, x, wide) * inter_weight + 2) >> 2, wide);
+        }
+}
+
+/* vvc_inter_template.c:78 */
+ORC_API void orc_put_gpm(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const int16_t *src0, const int16_t *src1, const uint8_t *weights, int step_x, int step_y)
+{
+    const int wide = bd > 8, shift = orc_max(5, 17 - bd), off = 1 << (shift - 1);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const int wgt = weights[(ptrdiff_t)y * step_y + (ptrdiff_t)x * step_x];
+            orc_st(dst + y * dst_stride, x,
+                   orc_clip_px((src0[y * ORC_PB + x] * wgt + src1[y * ORC_PB + x] * (8 - wgt) + off) >> shift, bd), wide);
+        }
+}
+
+/* ------------------------------------------------------------------ BDOF / PROF */
+
+/* vvc_inter_template.c:101 — one-sample ring of integer-position samples around the w x h int16 block */
+ORC_API void orc_bdof_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac,
+    int width, int height)
+{
+    const int wide = bd > 8, shift = 14 - bd;
+    const ptrdiff_t ss = src_stride >> wide;
+    const int x_off = (x_frac >> 3) - 1, y_off = (y_frac >> 3) - 1;
+    for (int y = -1; y <= height; y++)
+        for (int x = -1; x <= width; x++) {
+            if (y >= 0 && y < height && x >= 0 && x < width)
+                continue;                       /* interior untouched */
+            /* ring position (x, y) reads the pixel at (x + 1 + x_off, y + 1 + y_off) */
+            dst[y * ORC_PB + x] = (int16_t)(orc_ld(src, (ptrdiff_t)(y + 1 + y_off) * ss + (x + 1 + x_off), wide) << shift);
+        }
+}
+
+/* vvc_inter_template.c:130 */
+ORC_API void orc_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac)
+{
+    orc_bdof_fetch_samples(bd, dst, src, src_stride, x_frac, y_frac, 4, 4);
+}
+
+/* vvcdsp.c:29 — replicate the w x h block outward by one sample on every side (corners from the padded rows) */
+static void pad_ring_i16(int16_t *blk, ptrdiff_t stride, int w, int h)
+{
+    for (int y = 0; y < h; y++) {
+        blk[y * stride - 1] = blk[y * stride];
+        blk[y * stride + w] = blk[y * stride + w - 1];
+    }
+    for (int x = -1; x <= w; x++) {
+        blk[-stride + x] = blk[x];
+        blk[h * stride + x] = blk[(h - 1) * stride + x];
+    }
+}
+
+/* vvc_inter_template.c:135 — central differences of (sample >> 6); bd-independent */
+ORC_API void orc_prof_grad_filter(int bd, int16_t *gradient_h, int16_t *gradient_v, ptrdiff_t gradient_stride,
+    const int16_t *src, ptrdiff_t src_stride, int width, int height, int pad)
+{
+    (void)bd;
+    int16_t *gh = gradient_h + pad * (1 + gradient_stride);
+    int16_t *gv = gradient_v + pad * (1 + gradient_stride);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const int16_t *p = src + y * src_stride + x;
+            gh[y * gradient_stride + x] = (int16_t)((p[1] >> 6) - (p[-1] >> 6));
+            gv[y * gradient_stride + x] = (int16_t)((p[src_stride] >> 6) - (p[-src_stride] >> 6));
+        }
+    if (pad) {
+        pad_ring_i16(gradient_h + 1 + gradient_stride, gradient_stride, width, height);
+        pad_ring_i16(gradient_v + 1 + gradient_stride, gradient_stride, width, height);
+    }
+}
+
+/* shared 4x4 PROF refinement: vvc_inter_template.c:160,181,210.  mode 0 -> int16, 1 -> uni, 2 -> uni_w */
+static void prof_4x4(int bd, int mode, int16_t *dst16, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *dmx, const int16_t *dmy, int denom, int wx, int ox_in)
+{
+    const int wide = bd > 8;
+    const int limit = 1 << orc_max(13, bd + 1);
+    const int sh_uni = 14 - bd, off_uni = 1 << (sh_uni - 1);
+    const int sh_w = denom + orc_max(2, 14 - bd), off_w = 1 << (sh_w - 1);
+    const int ox = ox_in * (1 << (bd - 8));
+    int16_t gh[16], gv[16];
+    orc_prof_grad_filter(bd, gh, gv, 4, src, ORC_PB, 4, 4, 0);
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) {
+            const int o = y * 4 + x;
+            const int di = gh[o] * dmx[o] + gv[o] * dmy[o];
+            const int val = src[y * ORC_PB + x] + orc_clip3(di, -limit, limit - 1);
+            if (mode == 0)
+                dst16[y * ORC_PB + x] = (int16_t)val;
+            else if (mode == 1)
+                orc_st(dst + y * dst_stride, x, orc_clip_px((val + off_uni) >> sh_uni, bd), wide);
+            else
+                orc_st(dst + y * dst_stride, x, orc_clip_px(((val * wx + off_w) >> sh_w) + ox, bd), wide);
+        }
+}
+
+ORC_API void orc_apply_prof(int bd, int16_t *dst, const int16_t *src, const int16_t *diff_mv_x, const int16_t *diff_mv_y)
+{
+    prof_4x4(bd, 0, dst, NULL, 0, src, diff_mv_x, diff_mv_y, 0, 0, 0);
+}
+
+ORC_API void orc_apply_prof_uni(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y)
+{
+    prof_4x4(bd, 1, NULL, dst, dst_stride, src, diff_mv_x, diff_mv_y, 0, 0, 0);
+}
+
+ORC_API void orc_apply_prof_uni_w(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y, int denom, int wx, int ox)
+{
+    prof_4x4(bd, 2, NULL, dst, dst_stride, src, diff_mv_x, diff_mv_y, denom, wx, ox);
+}
+
+/*
+ * vvc_inter_template.c:288 — BDOF on a block of at most 16x16.  Gradients live in an 18x18 plane whose (1,1)
+ * is the block origin; src0/src1 are padded IN PLACE by one replicated ring (part of the slot's contract).
+ */
+#define BDOF_GS 18
+ORC_API void orc_apply_bdof(int bd, uint8_t *dst, ptrdiff_t dst_stride, int16_t *src0, int16_t *src1, int block_w, int block_h)
+{
+    const int wide = bd > 8;
+    const int sh = 15 - bd, off = 1 << (sh - 1);
+    int16_t gh[2][BDOF_GS * BDOF_GS], gv[2][BDOF_GS * BDOF_GS];
+
+    orc_prof_grad_filter(bd, gh[0], gv[0], BDOF_GS, src0, ORC_PB, block_w, block_h, 1);
+    pad_ring_i16(src0, ORC_PB, block_w, block_h);
+    orc_prof_grad_filter(bd, gh[1], gv[1], BDOF_GS, src1, ORC_PB, block_w, block_h, 1);
+    pad_ring_i16(src1, ORC_PB, block_w, block_h);
+
+    for (int by = 0; by < block_h; by += 4)
+        for (int bx = 0; bx < block_w; bx += 4) {
+            /* 6x6 window: samples (bx-1..bx+4, by-1..by+4); gradient plane index (by + j, bx + i) (:237-265) */
+            int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
+            for (int j = 0; j < 6; j++)
+                for (int i = 0; i < 6; i++) {
+                    const int so = (by - 1 + j) * ORC_PB + (bx - 1 + i);
+                    const int go = (by + j) * BDOF_GS + (bx + i);
+                    const int diff = (src0[so] >> 4) - (src1[so] >> 4);
+                    const int th = (gh[0][go] + gh[1][go]) >> 1;
+                    const int tv = (gv[0][go] + gv[1][go]) >> 1;
+                    sgx2 += orc_abs(th);
+                    sgy2 += orc_abs(tv);
+                    sgxgy += orc_sign(tv) * th;
+                    sgxdi += -orc_sign(th) * diff;
+                    sgydi += -orc_sign(tv) * diff;
+                }
+            const int vx = sgx2 > 0 ? orc_clip3((sgxdi * 4) >> orc_log2(sgx2), -15, 15) : 0;
+            const int vy = sgy2 > 0 ? orc_clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> orc_log2(sgy2), -15, 15) : 0;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) {
+                    const int so = (by + y) * ORC_PB + bx + x;
+                    const int go = (by + 1 + y) * BDOF_GS + (bx + 1 + x);
+                    const int corr = vx * (gh[0][go] - gh[1][go]) + vy * (gv[0][go] - gv[1][go]);
+                    orc_st(dst + (by + y) * dst_stride, bx + x, orc_clip_px((src0[so] + off + src1[so] + corr) >> sh, bd), wide);
+                }
+        }
+}
+
+/* ------------------------------------------------------------------ DMVR */
+
+/* vvcdsp.c:49 — SAD over every other row of two (w+4)x(h+4) bilinear planes displaced by ±(dx-2, dy-2) */
+ORC_API int orc_sad(const int16_t *src0, const int16_t *src1, int dx, int dy, int block_w, int block_h)
+{
+    int sad = 0;
+    dx -= 2;
+    dy -= 2;
+    src0 += (2 + dy) * ORC_PB + 2 + dx;
+    src1 += (2 - dy) * ORC_PB + 2 - dx;
+    for (int y = 0; y < block_h; y += 2)
+        for (int x = 0; x < block_w; x++)
+            sad += orc_abs(src0[y * ORC_PB + x] - src1[y * ORC_PB + x]);
+    return sad;
+}
+
+/* ff_vvc_inter_luma_dmvr_filters (vvc_data.c:1906): bilinear {16 - f, f}, f = 0..15 */
+ORC_INLINE int bil(int a, int b, int f) { return (16 - f) * a + f * b; }
+
+/* vvc_inter_template.c:324-413 — bilinear fetch to 10-bit precision */
+ORC_API void orc_dmvr(int bd, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int height,
+    intptr_t mx, intptr_t my, int width)
+{
+    const int wide = bd > 8;
+    const ptrdiff_t ss = src_stride >> wide;
+    const int sh1 = bd - 6, off1 = 1 << (sh1 - 1);
+    int16_t tmp[(ORC_PB + 1) * ORC_PB];
+
+    if (vfrac && hfrac)
+        for (int y = 0; y < height + 1; y++)
+            for (int x = 0; x < width; x++) {
+                const ptrdiff_t o = (ptrdiff_t)y * ss + x;
+                tmp[y * ORC_PB + x] = (int16_t)((bil(orc_ld(src, o, wide), orc_ld(src, o + 1, wide), (int)mx) + off1) >> sh1);
+            }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const ptrdiff_t o = (ptrdiff_t)y * ss + x;
+            int v;
+            if (vfrac && hfrac)
+                v = (bil(tmp[y * ORC_PB + x], tmp[(y + 1) * ORC_PB + x], (int)my) + 8) >> 4;
+            else if (hfrac)
+                v = (bil(orc_ld(src, o, wide), orc_ld(src, o + 1, wide), (int)mx) + off1) >> sh1;
+            else if (vfrac)
+                v = (bil(orc_ld(src, o, wide), orc_ld(src, o + ss, wide), (int)my) + off1) >> sh1;
+            else if (bd > 10)
+                v = (orc_ld(src, o, wide) + (1 << (bd - 11))) >> (bd - 10);
+            else
+                v = orc_ld(src, o, wide) << (10 - bd);
+            dst[y * ORC_PB + x] = (int16_t)v;
+        }
+}

@@ -1,0 +1,112 @@
+/*
+ * oracle/vvc_oracle.h — C API of the CPU oracle (TEST INFRASTRUCTURE ONLY; PARITY UNPINNED,
+ * see orc_common.h).  One function per slot of the reference's VVCDSPContext
+ * (libavcodec/vvc/vvcdsp.h:48-168): same argument order and meaning, with the bit depth the
+ * reference selects at ff_vvc_dsp_init() time (vvcdsp.c:228) passed as a leading `bd` argument,
+ * and table indices (luma/chroma, frac/int, h/v) passed as leading ints.
+ */
+#ifndef VVC_ORACLE_H
+#define VVC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* implicit source stride of sao.edge_filter: 2*MAX_PB_SIZE + AV_INPUT_BUFFER_PADDING_SIZE bytes (vvcdsp.h:140) */
+#define ORC_SAO_EDGE_SRC_STRIDE (2 * 128 + 64)
+
+/* ---- in-loop filters (orc_filter.c) ---- */
+void orc_lmcs_filter(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height, const uint8_t *lut);
+
+void orc_alf_filter_luma(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+    int width, int height, const int16_t *filter, const int16_t *clip, int vb_pos);
+void orc_alf_filter_chroma(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
+    int width, int height, const int16_t *filter, const int16_t *clip, int vb_pos);
+void orc_alf_filter_cc(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *luma, ptrdiff_t luma_stride,
+    int width, int height, int hs, int vs, const int16_t *filter, int vb_pos);
+void orc_alf_classify(int bd, int *class_idx, int *transpose_idx, const uint8_t *src, ptrdiff_t src_stride,
+    int width, int height, int vb_pos, int *gradient_tmp);
+void orc_alf_recon_coeff_and_clip(int bd, int16_t *coeff, int16_t *clip, const int *class_idx, const int *transpose_idx,
+    int size, const int16_t *coeff_set, const uint8_t *clip_idx_set, const uint8_t *class_to_filt);
+extern const uint8_t orc_alf_transpose_perm[4][12];
+
+void orc_sao_band_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+    const int16_t *sao_offset_val, int sao_left_class, int width, int height);
+void orc_sao_edge_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride,
+    const int16_t *sao_offset_val, int eo, int width, int height);
+/* SAOParams flattened: offset_val = sao->offset_val[c_idx], eo_class = sao->eo_class[c_idx] */
+void orc_sao_edge_restore(int bd, int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+    const int16_t *offset_val, int eo_class, const int *borders, int width, int height,
+    const uint8_t *vert_edge, const uint8_t *horiz_edge, const uint8_t *diag_edge);
+
+/* dir: 0 = the [h] slot (horizontal edge), 1 = the [v] slot (vertical edge) */
+void orc_lf_filter_luma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+    const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int hor_ctu_edge);
+void orc_lf_filter_chroma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+    const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int shift);
+int orc_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t stride);
+
+/* ---- inter prediction (orc_inter.c) ---- */
+/* kind: 0 = put (int16 dst, stride 128), 1 = put_uni, 2 = put_uni_w.  vfrac/hfrac = the [!!my][!!mx] indices. */
+void orc_put(int bd, int chroma, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride,
+    int height, const int8_t *hf, const int8_t *vf, int width);
+void orc_put_uni(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, const int8_t *hf, const int8_t *vf, int width);
+void orc_put_uni_w(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, int denom, int wx, int ox,
+    const int8_t *hf, const int8_t *vf, int width);
+void orc_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height);
+void orc_w_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height,
+    int denom, int w0, int w1, int o0, int o1);
+void orc_put_ciip(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const uint8_t *inter, ptrdiff_t inter_stride, int intra_weight);
+void orc_put_gpm(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const int16_t *src0, const int16_t *src1, const uint8_t *weights, int step_x, int step_y);
+void orc_bdof_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac,
+    int width, int height);
+void orc_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac);
+void orc_prof_grad_filter(int bd, int16_t *gradient_h, int16_t *gradient_v, ptrdiff_t gradient_stride,
+    const int16_t *src, ptrdiff_t src_stride, int width, int height, int pad);
+void orc_apply_prof(int bd, int16_t *dst, const int16_t *src, const int16_t *diff_mv_x, const int16_t *diff_mv_y);
+void orc_apply_prof_uni(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y);
+void orc_apply_prof_uni_w(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y, int denom, int wx, int ox);
+void orc_apply_bdof(int bd, uint8_t *dst, ptrdiff_t dst_stride, int16_t *src0, int16_t *src1, int block_w, int block_h);
+int  orc_sad(const int16_t *src0, const int16_t *src1, int dx, int dy, int block_w, int block_h);
+void orc_dmvr(int bd, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int height,
+    intptr_t mx, intptr_t my, int width);
+
+/* ---- inverse transform + residual (orc_itx.c) ---- */
+enum { ORC_DCT2 = 0, ORC_DST7 = 1, ORC_DCT8 = 2 };
+/* 1-D kernels on a strided int vector; n = 1,2,4,..,64 (DCT2) or 1,4,8,16,32 (DST7/DCT8) */
+void orc_inv_tx_1d(int type, int n, int *coeffs, ptrdiff_t stride, size_t nz);
+/* itx.itx[trh][trv][log2 w][log2 h]; returns 0, or -1 when the reference table has no entry for that combination */
+int  orc_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
+    intptr_t log2_transform_range, intptr_t bd);
+void orc_inv_lfnst_1d(int *v, const int *u, int no_zero_size, int n_tr_s, int pred_mode_intra, int lfnst_idx,
+    int log2_transform_range);
+void orc_add_residual(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride);
+void orc_add_residual_joint(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride, int c_sign, int shift);
+void orc_pred_residual_joint(int *buf, int width, int height, int c_sign, int shift);
+void orc_transform_bdpcm(int *coeffs, int width, int height, int vertical, int log2_transform_range);
+
+/* ---- intra leaf predictors (orc_intra.c) ---- */
+void orc_pred_planar(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);
+void orc_pred_dc(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);
+void orc_pred_v(int bd, uint8_t *src, const uint8_t *top, int w, int h, ptrdiff_t stride);
+void orc_pred_h(int bd, uint8_t *src, const uint8_t *left, int w, int h, ptrdiff_t stride);
+void orc_pred_angular_v(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc);
+void orc_pred_angular_h(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc);
+void orc_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int mode_id, int is_transpose);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

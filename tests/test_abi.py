@@ -1,0 +1,35 @@
+"""CPU: the product library loads and exports every entry point that include/*.h declares (no compute calls)."""
+import ctypes
+import glob
+import os
+import re
+
+from conftest import ROOT
+from ffvvc_amd import abi
+
+
+def declared_symbols():
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(vvc355_\w+|ff_vvc_dsp_init_mi355)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(abi.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) > 10
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_python_binding_covers_every_declared_symbol():
+    bound = {"vvc355_" + k for t in (abi.SLOT_SIGNATURES, abi.RUNTIME_SIGNATURES, abi.BATCH_SIGNATURES) for k in t}
+    names = {n for n in declared_symbols() if n.startswith("vvc355_")}
+    assert names == bound, f"only in header: {sorted(names - bound)}; only in binding: {sorted(bound - names)}"
+
+
+def test_job_struct_sizes_match_header():
+    assert ctypes.sizeof(abi.AlfJob) == 64
