@@ -29,6 +29,23 @@ SLOT_SIGNATURES = {
     "alf_filter_cc":            ("v", "ipqpqiiiipi"),
     "alf_classify":             ("v", "ipppqiiip"),
     "alf_recon_coeff_and_clip": ("v", "ippppippp"),
+    # ---- inter
+    "put":                ("v", "iiiippqippi"),
+    "put_uni":            ("v", "iiiipqpqippi"),
+    "put_uni_w":          ("v", "iiiipqpqiiiippi"),
+    "avg":                ("v", "ipqppii"),
+    "w_avg":              ("v", "ipqppiiiiiii"),
+    "put_ciip":           ("v", "ipqiipqi"),
+    "put_gpm":            ("v", "ipqiipppii"),
+    "fetch_samples":      ("v", "ippqii"),
+    "bdof_fetch_samples": ("v", "ippqiiii"),
+    "prof_grad_filter":   ("v", "ippqpqiii"),
+    "apply_prof":         ("v", "ipppp"),
+    "apply_prof_uni":     ("v", "ipqppp"),
+    "apply_prof_uni_w":   ("v", "ipqpppiii"),
+    "apply_bdof":         ("v", "ipqppii"),
+    "sad":                ("i", "ppiiii"),
+    "dmvr":               ("v", "iiippqiqqi"),
 }
 
 RUNTIME_SIGNATURES = {
@@ -48,6 +65,9 @@ BATCH_SIGNATURES = {
     "alf_luma_batch":   ("v", "piipi"),
     "alf_chroma_batch": ("v", "pipi"),
     "alf_cc_batch":     ("v", "pipi"),
+    "mc_batch":         ("v", "pipiii"),
+    "blend_batch":      ("v", "pipiii"),
+    "bdof_batch":       ("v", "pipi"),
 }
 
 
@@ -87,4 +107,28 @@ class AlfJob(ctypes.Structure):
         ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("vb_pos", ctypes.c_int16),
         ("ext_l", ctypes.c_int8), ("ext_r", ctypes.c_int8), ("ext_t", ctypes.c_int8), ("ext_b", ctypes.c_int8),
         ("hs", ctypes.c_int8), ("vs", ctypes.c_int8), ("pad_", ctypes.c_int8 * 4),
+    ]
+
+
+class McJob(ctypes.Structure):
+    """Mirror of vvc355_mc_job."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("src", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("src_stride", ctypes.c_int32),
+        ("w", ctypes.c_int16), ("h", ctypes.c_int16),
+        ("hf", ctypes.c_int8 * 8), ("vf", ctypes.c_int8 * 8),
+        ("kind", ctypes.c_uint8), ("chroma", ctypes.c_uint8), ("hfrac", ctypes.c_uint8), ("vfrac", ctypes.c_uint8),
+        ("denom", ctypes.c_int16), ("wx", ctypes.c_int16), ("ox", ctypes.c_int16), ("pad_", ctypes.c_int16),
+    ]
+
+
+class BlendJob(ctypes.Structure):
+    """Mirror of vvc355_blend_job."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("src0", ctypes.c_uint64), ("src1", ctypes.c_uint64), ("aux", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("src0_stride", ctypes.c_int32), ("src1_stride", ctypes.c_int32),
+        ("step_x", ctypes.c_int32), ("step_y", ctypes.c_int32),
+        ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("mode", ctypes.c_int16), ("denom", ctypes.c_int16),
+        ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
+        ("pad_", ctypes.c_int32),
     ]

@@ -42,6 +42,14 @@ void  vvc355_stream_destroy(void *stream);
 void  vvc355_stream_sync(void *stream);          /* NULL = the default stream */
 const char *vvc355_version(void);
 
+/* ------------------------------------------------------------------ constant tables (tables.cpp) */
+/* H.266 tables, flat: the same data libavcodec/vvc/vvc_data.c:1735 (luma [3][16][8]) and :1798 (chroma [3][32][4]) hold */
+extern const int8_t vvc355_tab_inter_luma_filters[3 * 16 * 8];
+extern const int8_t vvc355_tab_inter_chroma_filters[3 * 32 * 4];
+extern const int16_t vvc355_tab_alf_fix_filt_coeff[64 * 12];          /* vvc_data.c:1644 */
+extern const uint8_t vvc355_tab_alf_class_to_filt_map[16 * 25];       /* vvc_data.c:1712 */
+extern const uint8_t vvc355_tab_alf_aps_class_to_filt_map[25];        /* vvc_data.c:1731 */
+
 /* ------------------------------------------------------------------ ALF (alf.hip) */
 
 /*
@@ -90,6 +98,80 @@ void vvc355_alf_classify(int bd, int *class_idx, int *transpose_idx, const uint8
 /* VVCALFDSPContext.recon_coeff_and_clip — vvcdsp.h:156, vvc_filter_template.c:383 */
 void vvc355_alf_recon_coeff_and_clip(int bd, int16_t *coeff, int16_t *clip, const int *class_idx, const int *transpose_idx,
     int size, const int16_t *coeff_set, const uint8_t *clip_idx_set, const uint8_t *class_to_filt);
+
+/* ------------------------------------------------------------------ inter prediction (inter.hip) */
+
+/* One motion-compensated block: put (kind 0: int16 dst, 14-bit scaled), put_uni (1) or put_uni_w (2).
+ * src = DEVICE address of the block's integer-position sample in the reference plane; the kernel reads the
+ * 3/4 (luma) or 1/2 (chroma) sample apron the filter needs, so edge emulation (vvc_inter.c:33-110) must already
+ * have been applied by whoever built the plane (padded reference planes). */
+typedef struct vvc355_mc_job {
+    uint64_t dst;
+    uint64_t src;
+    int32_t  dst_stride;     /* bytes (put slot: 256 = MAX_PB_SIZE int16) */
+    int32_t  src_stride;     /* bytes */
+    int16_t  w, h;
+    int8_t   hf[8], vf[8];   /* filter taps: 8 luma / 4 chroma (dmvr: hf[0] = mx, vf[0] = my) */
+    uint8_t  kind, chroma, hfrac, vfrac;
+    int16_t  denom, wx, ox;  /* put_uni_w */
+    int16_t  pad_;
+} vvc355_mc_job;
+
+/* Element-wise work on two operands: mode 0 avg, 1 w_avg, 2 put_ciip (src0 = inter pixels, w0 = intra weight),
+ * 3 put_gpm (aux = weight mask, step_x/step_y); also the descriptor of bdof / prof / sad / ring-fetch jobs. */
+typedef struct vvc355_blend_job {
+    uint64_t dst;
+    uint64_t src0;
+    uint64_t src1;
+    uint64_t aux;
+    int32_t  dst_stride, src0_stride, src1_stride;   /* bytes */
+    int32_t  step_x, step_y;
+    int16_t  w, h, mode, denom, w0, w1, o0, o1;
+    int32_t  pad_;
+} vvc355_blend_job;
+
+void vvc355_mc_batch(void *stream, int bd, const vvc355_mc_job *jobs_dev, int n_jobs, int max_w, int max_h);
+void vvc355_blend_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs, int max_w, int max_h);
+void vvc355_bdof_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs);
+
+/* VVCInterDSPContext.put[chroma][*][vfrac][hfrac] — vvcdsp.h:49, h2656_inter_template.c:29,97,112,127,342,357,372 */
+void vvc355_put(int bd, int chroma, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride,
+    int height, const int8_t *hf, const int8_t *vf, int width);
+/* .put_uni — vvcdsp.h:53, h2656_inter_template.c:44,154,180,207,401,425,449 */
+void vvc355_put_uni(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, const int8_t *hf, const int8_t *vf, int width);
+/* .put_uni_w — vvcdsp.h:57, h2656_inter_template.c:60,247,273,299,487,513,540 */
+void vvc355_put_uni_w(int bd, int chroma, int vfrac, int hfrac, uint8_t *dst, ptrdiff_t dst_stride,
+    const uint8_t *src, ptrdiff_t src_stride, int height, int denom, int wx, int ox,
+    const int8_t *hf, const int8_t *vf, int width);
+/* .avg / .w_avg — vvcdsp.h:61,64, vvc_inter_template.c:25,42 */
+void vvc355_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height);
+void vvc355_w_avg(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src0, const int16_t *src1, int width, int height,
+    int denom, int w0, int w1, int o0, int o1);
+/* .put_ciip / .put_gpm — vvcdsp.h:68,71, vvc_inter_template.c:60,78 */
+void vvc355_put_ciip(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const uint8_t *inter, ptrdiff_t inter_stride, int intra_weight);
+void vvc355_put_gpm(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height,
+    const int16_t *src0, const int16_t *src1, const uint8_t *weights, int step_x, int step_y);
+/* .fetch_samples / .bdof_fetch_samples — vvcdsp.h:75,76, vvc_inter_template.c:130,101 */
+void vvc355_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac);
+void vvc355_bdof_fetch_samples(int bd, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int x_frac, int y_frac,
+    int width, int height);
+/* .prof_grad_filter / .apply_prof* — vvcdsp.h:79-87, vvc_inter_template.c:135,160,181,210 */
+void vvc355_prof_grad_filter(int bd, int16_t *gradient_h, int16_t *gradient_v, ptrdiff_t gradient_stride,
+    const int16_t *src, ptrdiff_t src_stride, int width, int height, int pad);
+void vvc355_apply_prof(int bd, int16_t *dst, const int16_t *src, const int16_t *diff_mv_x, const int16_t *diff_mv_y);
+void vvc355_apply_prof_uni(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y);
+void vvc355_apply_prof_uni_w(int bd, uint8_t *dst, ptrdiff_t dst_stride, const int16_t *src,
+    const int16_t *diff_mv_x, const int16_t *diff_mv_y, int denom, int wx, int ox);
+/* .apply_bdof — vvcdsp.h:89, vvc_inter_template.c:288 (pads src0/src1 in place, like the reference) */
+void vvc355_apply_bdof(int bd, uint8_t *dst, ptrdiff_t dst_stride, int16_t *src0, int16_t *src1, int block_w, int block_h);
+/* .sad — vvcdsp.h:91, vvcdsp.c:49 (bit-depth independent) */
+int  vvc355_sad(const int16_t *src0, const int16_t *src1, int dx, int dy, int block_w, int block_h);
+/* .dmvr[vfrac][hfrac] — vvcdsp.h:92, vvc_inter_template.c:324,347,365,384 */
+void vvc355_dmvr(int bd, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int height,
+    intptr_t mx, intptr_t my, int width);
 
 #ifdef __cplusplus
 }
