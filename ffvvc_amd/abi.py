@@ -46,6 +46,14 @@ SLOT_SIGNATURES = {
     "apply_bdof":         ("v", "ipqppii"),
     "sad":                ("i", "ppiiii"),
     "dmvr":               ("v", "iiippqiqqi"),
+    # ---- LMCS / SAO / deblock
+    "lmcs_filter":        ("v", "ipqiip"),
+    "sao_band_filter":    ("v", "ippqqpiii"),
+    "sao_edge_filter":    ("v", "ippqpiii"),
+    "sao_edge_restore":   ("v", "iippqqpipiippp"),
+    "lf_filter_luma":     ("v", "iipqppppppi"),
+    "lf_filter_chroma":   ("v", "iipqppppppi"),
+    "lf_ladf_level":      ("i", "iipq"),
 }
 
 RUNTIME_SIGNATURES = {
@@ -68,6 +76,9 @@ BATCH_SIGNATURES = {
     "mc_batch":         ("v", "pipiii"),
     "blend_batch":      ("v", "pipiii"),
     "bdof_batch":       ("v", "pipi"),
+    "sao_batch":        ("v", "pipiii"),
+    "deblock_batch":    ("v", "pipi"),
+    "lmcs_batch":       ("v", "pipiii"),
 }
 
 
@@ -131,4 +142,27 @@ class BlendJob(ctypes.Structure):
         ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("mode", ctypes.c_int16), ("denom", ctypes.c_int16),
         ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
         ("pad_", ctypes.c_int32),
+    ]
+
+
+class SaoJob(ctypes.Structure):
+    """Mirror of vvc355_sao_job."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("src", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("src_stride", ctypes.c_int32),
+        ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("offset_val", ctypes.c_int16 * 5),
+        ("type", ctypes.c_uint8), ("eo", ctypes.c_uint8), ("band_position", ctypes.c_uint8), ("restore", ctypes.c_uint8),
+        ("borders", ctypes.c_uint8 * 4), ("vert_edge", ctypes.c_uint8 * 2), ("horiz_edge", ctypes.c_uint8 * 2),
+        ("diag_edge", ctypes.c_uint8 * 4), ("pad_", ctypes.c_uint8 * 2),
+    ]
+
+
+class DeblockJob(ctypes.Structure):
+    """Mirror of vvc355_deblock_job."""
+    _fields_ = [
+        ("pix", ctypes.c_uint64), ("stride", ctypes.c_int32),
+        ("beta", ctypes.c_int32 * 4), ("tc", ctypes.c_int32 * 4),
+        ("no_p", ctypes.c_uint8 * 4), ("no_q", ctypes.c_uint8 * 4),
+        ("max_len_p", ctypes.c_uint8 * 4), ("max_len_q", ctypes.c_uint8 * 4),
+        ("dir", ctypes.c_uint8), ("chroma", ctypes.c_uint8), ("flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
     ]

@@ -1,0 +1,498 @@
+// In-loop filter kernels for gfx950 other than ALF: LMCS luma mapping, SAO (band / edge / edge-restore) and the
+// deblocking filter (luma incl. the long-tap filters, chroma, LADF level).
+//
+// Reference behaviour: libavcodec/vvc/vvc_filter_template.c:25 (lmcs), :466-804 (deblock decisions + long filters),
+// libavcodec/h26x/h2656_sao_template.c:24-215, libavcodec/h26x/h2656_deblock_template.c:25-99, and for the batched SAO
+// stage the caller's border rules libavcodec/vvc/vvc_filter.c:154-300.
+#include "common.hpp"
+#include "runtime.hpp"
+#include "../../include/vvc_mi355.h"
+
+namespace vvc355 {
+
+// ------------------------------------------------------------------------------------------------ LMCS
+
+// job.src0 = LUT (pixel-typed, 2^bd entries); in place on job.dst
+template <int BD>
+__global__ __launch_bounds__(256) void lmcs_kernel(const vvc355_blend_job *__restrict__ jobs)
+{
+    const vvc355_blend_job job = jobs[blockIdx.y];
+    const uint8_t *lut = (const uint8_t *)job.src0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
+        const int y = i / job.w, x = i - y * job.w;
+        uint8_t *row = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
+        st_px<BD>(row, x, ld_px<BD>(lut, ld_px<BD>(row, x)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SAO
+
+__device__ static const uint8_t kSaoCat[5] = { 1, 2, 0, 3, 4 };
+__device__ static const int8_t kSaoNb[4][4] = { { -1, 0, 1, 0 }, { 0, -1, 0, 1 }, { -1, -1, 1, 1 }, { 1, -1, -1, 1 } };
+
+// true when restore rules of h2656_sao_template.c:81/:131 override sample (x, y); `v` receives the value
+template <int BD>
+__device__ __forceinline__ bool sao_restore_px(const vvc355_sao_job &job, int x, int y, int src_px, int &v)
+{
+    const int w = job.w, h = job.h, eo = job.eo;
+    const int off0 = job.offset_val[0];
+    int x0 = 0, y0 = 0, x1 = w, y1 = h;
+    bool hit = false;
+    if (eo != 1) {
+        if (job.borders[0]) { if (x == 0) { v = clip_px<BD>(src_px + off0); hit = true; } x0 = 1; }
+        if (job.borders[2]) { if (x == w - 1) { v = clip_px<BD>(src_px + off0); hit = true; } x1--; }
+    }
+    if (eo != 0) {
+        if (job.borders[1]) { if (y == 0 && x >= x0 && x < x1) { v = clip_px<BD>(src_px + off0); hit = true; } if (job.restore) y0 = 1; }
+        if (job.borders[3]) { if (y == h - 1 && x >= x0 && x < x1) { v = clip_px<BD>(src_px + off0); hit = true; } y1--; }
+    }
+    if (job.restore) {
+        const int keep_ul = !job.diag_edge[0] && eo == 2 && !job.borders[0] && !job.borders[1];
+        const int keep_ur = !job.diag_edge[1] && eo == 3 && !job.borders[1] && !job.borders[2];
+        const int keep_lr = !job.diag_edge[2] && eo == 2 && !job.borders[2] && !job.borders[3];
+        const int keep_ll = !job.diag_edge[3] && eo == 3 && !job.borders[0] && !job.borders[3];
+        bool r = false;
+        r |= job.vert_edge[0] && eo != 1 && x == 0 && y >= y0 + keep_ul && y < y1 - keep_ll;
+        r |= job.vert_edge[1] && eo != 1 && x == x1 - 1 && y >= y0 + keep_ur && y < y1 - keep_lr;
+        r |= job.horiz_edge[0] && eo != 0 && y == 0 && x >= x0 + keep_ul && x < x1 - keep_ur;
+        r |= job.horiz_edge[1] && eo != 0 && y == y1 - 1 && x >= x0 + keep_ll && x < x1 - keep_lr;
+        r |= job.diag_edge[0] && eo == 2 && x == 0 && y == 0;
+        r |= job.diag_edge[1] && eo == 3 && x == x1 - 1 && y == 0;
+        r |= job.diag_edge[2] && eo == 2 && x == x1 - 1 && y == y1 - 1;
+        r |= job.diag_edge[3] && eo == 3 && x == 0 && y == y1 - 1;
+        if (r) { v = src_px; hit = true; }
+    }
+    return hit;
+}
+
+// type: 1 band (:24), 2 edge (:50), 3 edge + restore fused (batched stage), 4 restore only (edge_restore slot)
+template <int BD>
+__global__ __launch_bounds__(256) void sao_kernel(const vvc355_sao_job *__restrict__ jobs)
+{
+    const vvc355_sao_job job = jobs[blockIdx.y];
+    const int w = job.w, h = job.h, type = job.type;
+    const uint8_t *src = (const uint8_t *)job.src;
+    const ptrdiff_t ss = job.src_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    int band[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) band[k] = (k + job.band_position) & 31;
+    const int eo = job.eo & 3;
+    const ptrdiff_t oa = kSaoNb[eo][0] + kSaoNb[eo][1] * ss, ob = kSaoNb[eo][2] + kSaoNb[eo][3] * ss;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w * h; i += gridDim.x * blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        const ptrdiff_t o = (ptrdiff_t)y * ss + x;
+        const int s = ld_px<BD>(src, o);
+        uint8_t *drow = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
+        int v = s;
+        if (type == 1) {
+            const int b = (s >> (BD - 5)) & 31;
+            int off = 0;
+            // later table writes win when band positions wrap onto each other (:38-39)
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
+            st_px<BD>(drow, x, clip_px<BD>(s + off));
+            continue;
+        }
+        if (type == 4) {
+            if (sao_restore_px<BD>(job, x, y, s, v))
+                st_px<BD>(drow, x, v);
+            continue;
+        }
+        if (type == 3 && sao_restore_px<BD>(job, x, y, s, v)) {
+            st_px<BD>(drow, x, v);
+            continue;
+        }
+        const int k = 2 + sign_of(s - ld_px<BD>(src, o + oa)) + sign_of(s - ld_px<BD>(src, o + ob));
+        st_px<BD>(drow, x, clip_px<BD>(s + job.offset_val[kSaoCat[k]]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ deblock
+
+// view of one 4-line (or 2-line) segment: p[i] at pix - (i+1)*xs, q[i] at pix + i*xs, lines ys apart (in pixels)
+template <int BD> struct Dbk {
+    uint8_t *pix;
+    ptrdiff_t xs, ys;
+    __device__ __forceinline__ int p(int l, int i) const { return ld_px<BD>(pix, l * ys - (i + 1) * xs); }
+    __device__ __forceinline__ int q(int l, int i) const { return ld_px<BD>(pix, l * ys + i * xs); }
+    __device__ __forceinline__ void sp(int l, int i, int v) const { st_px<BD>(pix, l * ys - (i + 1) * xs, v); }
+    __device__ __forceinline__ void sq(int l, int i, int v) const { st_px<BD>(pix, l * ys + i * xs, v); }
+};
+__device__ __forceinline__ int d2(int a, int b, int c) { return abs(a - 2 * b + c); }
+
+__device__ static const uint8_t kW3[3] = { 53, 32, 11 }, kW5[5] = { 58, 45, 32, 19, 6 }, kW7[7] = { 59, 50, 41, 32, 23, 14, 5 };
+__device__ static const uint8_t kT3[3] = { 6, 4, 2 }, kT5[5] = { 6, 5, 4, 3, 2 }, kT7[7] = { 6, 5, 4, 3, 2, 1, 1 };
+
+template <int BD>
+__device__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int len_p, int len_q)
+{
+    for (int l = 0; l < 4; l++) {
+        int p[8], q[8], m;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { p[i] = d.p(l, i); q[i] = d.q(l, i); }
+        if (len_p == 5 && len_q == 5)
+            m = (p[4] + p[3] + 2 * (p[2] + p[1] + p[0] + q[0] + q[1] + q[2]) + q[3] + q[4] + 8) >> 4;
+        else if (len_p == len_q)
+            m = (p[6] + p[5] + p[4] + p[3] + p[2] + p[1] + 2 * (p[0] + q[0]) + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + 8) >> 4;
+        else if (len_p + len_q == 12)
+            m = (p[5] + p[4] + p[3] + p[2] + 2 * (p[1] + p[0] + q[0] + q[1]) + q[2] + q[3] + q[4] + q[5] + 8) >> 4;
+        else if (len_p + len_q == 8)
+            m = (p[3] + p[2] + p[1] + p[0] + q[0] + q[1] + q[2] + q[3] + 4) >> 3;
+        else if (len_q == 7)
+            m = (2 * (p[2] + p[1] + p[0] + q[0]) + p[0] + p[1] + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + 8) >> 4;
+        else
+            m = (p[6] + p[5] + p[4] + p[3] + p[2] + p[1] + 2 * (q[2] + q[1] + q[0] + p[0]) + q[0] + q[1] + 8) >> 4;
+        if (!no_p) {
+            const int n = len_p == 3 ? 3 : len_p == 5 ? 5 : 7;
+            const uint8_t *wt = n == 3 ? kW3 : n == 5 ? kW5 : kW7, *tt = n == 3 ? kT3 : n == 5 ? kT5 : kT7;
+            int ref = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i == len_p || i == len_p - 1) ref += p[i];
+            ref = (ref + 1) >> 1;
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+                if (i < n) {
+                    const int lim = (tc * tt[i]) >> 1;
+                    d.sp(l, i, p[i] + clip3(((m * wt[i] + ref * (64 - wt[i]) + 32) >> 6) - p[i], -lim, lim));
+                }
+        }
+        if (!no_q) {
+            const int n = len_q == 3 ? 3 : len_q == 5 ? 5 : 7;
+            const uint8_t *wt = n == 3 ? kW3 : n == 5 ? kW5 : kW7, *tt = n == 3 ? kT3 : n == 5 ? kT5 : kT7;
+            int ref = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i == len_q || i == len_q - 1) ref += q[i];
+            ref = (ref + 1) >> 1;
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+                if (i < n) {
+                    const int lim = (tc * tt[i]) >> 1;
+                    d.sq(l, i, q[i] + clip3(((m * wt[i] + ref * (64 - wt[i]) + 32) >> 6) - q[i], -lim, lim));
+                }
+        }
+    }
+}
+
+template <int BD>
+__device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q, int hor_ctu_edge)
+{
+    const int tc = BD < 10 ? (tc_in + (1 << (9 - BD))) >> (10 - BD) : tc_in << (BD - 10);
+    if (!tc)
+        return;
+    const int dp0 = d2(d.p(0, 2), d.p(0, 1), d.p(0, 0)), dq0 = d2(d.q(0, 2), d.q(0, 1), d.q(0, 0));
+    const int dp3 = d2(d.p(3, 2), d.p(3, 1), d.p(3, 0)), dq3 = d2(d.q(3, 2), d.q(3, 1), d.q(3, 0));
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    const int tc25 = (tc * 5 + 1) >> 1;
+    const int large_p = len_p > 3 && !hor_ctu_edge, large_q = len_q > 3;
+    const int beta = beta_in << (BD - 8);
+
+    if (large_p || large_q) {
+        const int dp0l = large_p ? (dp0 + d2(d.p(0, 5), d.p(0, 4), d.p(0, 3)) + 1) >> 1 : dp0;
+        const int dq0l = large_q ? (dq0 + d2(d.q(0, 5), d.q(0, 4), d.q(0, 3)) + 1) >> 1 : dq0;
+        const int dp3l = large_p ? (dp3 + d2(d.p(3, 5), d.p(3, 4), d.p(3, 3)) + 1) >> 1 : dp3;
+        const int dq3l = large_q ? (dq3 + d2(d.q(3, 5), d.q(3, 4), d.q(3, 3)) + 1) >> 1 : dq3;
+        const int d0l = dp0l + dq0l, d3l = dp3l + dq3l;
+        const int beta53 = (beta * 3) >> 5, beta_4 = beta >> 4;
+        len_p = large_p ? len_p : 3;
+        len_q = large_q ? len_q : 3;
+        if (d0l + d3l < beta) {
+            const int sp0l = abs(d.p(0, 3) - d.p(0, 0)) + (len_p == 7 ? abs(d.p(0, 7) - d.p(0, 6) - d.p(0, 5) + d.p(0, 4)) : 0);
+            const int sq0l = abs(d.q(0, 0) - d.q(0, 3)) + (len_q == 7 ? abs(d.q(0, 4) - d.q(0, 5) - d.q(0, 6) + d.q(0, 7)) : 0);
+            const int sp3l = abs(d.p(3, 3) - d.p(3, 0)) + (len_p == 7 ? abs(d.p(3, 7) - d.p(3, 6) - d.p(3, 5) + d.p(3, 4)) : 0);
+            const int sq3l = abs(d.q(3, 0) - d.q(3, 3)) + (len_q == 7 ? abs(d.q(3, 4) - d.q(3, 5) - d.q(3, 6) + d.q(3, 7)) : 0);
+            const int sp0 = large_p ? (sp0l + abs(d.p(0, 3) - d.p(0, len_p)) + 1) >> 1 : sp0l;
+            const int sp3 = large_p ? (sp3l + abs(d.p(3, 3) - d.p(3, len_p)) + 1) >> 1 : sp3l;
+            const int sq0 = large_q ? (sq0l + abs(d.q(0, 3) - d.q(0, len_q)) + 1) >> 1 : sq0l;
+            const int sq3 = large_q ? (sq3l + abs(d.q(3, 3) - d.q(3, len_q)) + 1) >> 1 : sq3l;
+            if (sp0 + sq0 < beta53 && abs(d.p(0, 0) - d.q(0, 0)) < tc25 &&
+                sp3 + sq3 < beta53 && abs(d.p(3, 0) - d.q(3, 0)) < tc25 &&
+                (d0l << 1) < beta_4 && (d3l << 1) < beta_4) {
+                dbk_luma_large<BD>(d, tc, no_p, no_q, len_p, len_q);
+                return;
+            }
+        }
+    }
+    if (d0 + d3 >= beta)
+        return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2;
+    if (len_p > 2 && len_q > 2 &&
+        abs(d.p(0, 3) - d.p(0, 0)) + abs(d.q(0, 3) - d.q(0, 0)) < beta_3 && abs(d.p(0, 0) - d.q(0, 0)) < tc25 &&
+        abs(d.p(3, 3) - d.p(3, 0)) + abs(d.q(3, 3) - d.q(3, 0)) < beta_3 && abs(d.p(3, 0) - d.q(3, 0)) < tc25 &&
+        (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        // strong filter, h2656_deblock_template.c:25
+        const int tc2 = tc << 1, tc3 = tc * 3;
+        for (int l = 0; l < 4; l++) {
+            const int p3 = d.p(l, 3), p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
+            const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2), q3 = d.q(l, 3);
+            if (!no_p) {
+                d.sp(l, 0, p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -tc3, tc3));
+                d.sp(l, 1, p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -tc2, tc2));
+                d.sp(l, 2, p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -tc, tc));
+            }
+            if (!no_q) {
+                d.sq(l, 0, q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -tc3, tc3));
+                d.sq(l, 1, q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -tc2, tc2));
+                d.sq(l, 2, q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -tc, tc));
+            }
+        }
+    } else {
+        // weak filter, h2656_deblock_template.c:52
+        int nd_p = 1, nd_q = 1;
+        if (len_p > 1 && len_q > 1) {
+            const int side = (beta + (beta >> 1)) >> 3;
+            if (dp0 + dp3 < side) nd_p = 2;
+            if (dq0 + dq3 < side) nd_q = 2;
+        }
+        const int tc_2 = tc >> 1;
+        for (int l = 0; l < 4; l++) {
+            const int p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
+            const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2);
+            int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (abs(delta) >= 10 * tc)
+                continue;
+            delta = clip3(delta, -tc, tc);
+            if (!no_p) d.sp(l, 0, clip_px<BD>(p0 + delta));
+            if (!no_q) d.sq(l, 0, clip_px<BD>(q0 - delta));
+            if (!no_p && nd_p > 1) d.sp(l, 1, clip_px<BD>(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2)));
+            if (!no_q && nd_q > 1) d.sq(l, 1, clip_px<BD>(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2)));
+        }
+    }
+}
+
+template <int BD>
+__device__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q)
+{
+    const int tc = BD < 10 ? (tc_in + (1 << (9 - BD))) >> (10 - BD) : tc_in << (BD - 10);
+    if (!tc || !len_p || !len_q)
+        return;
+    const int l2 = lines == 2 ? 1 : 3;
+    const int beta = beta_in << (BD - 8), beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (len_q == 3) {
+        const bool one = len_p == 1;
+        const int p0 = d.p(0, 0), p1 = d.p(0, 1), p2 = one ? p1 : d.p(0, 2), p3 = one ? p1 : d.p(0, 3);
+        const int p0n = d.p(l2, 0), p1n = d.p(l2, 1), p2n = one ? p1n : d.p(l2, 2);
+        const int q0 = d.q(0, 0), q1 = d.q(0, 1), q2 = d.q(0, 2), q3 = d.q(0, 3);
+        const int q0n = d.q(l2, 0), q1n = d.q(l2, 1), q2n = d.q(l2, 2);
+        const int dd0 = d2(p2, p1, p0) + d2(q2, q1, q0), dd1 = d2(p2n, p1n, p0n) + d2(q2n, q1n, q0n);
+        bool strong = false;
+        if (dd0 + dd1 < beta) {
+            const int p3n = one ? p1n : d.p(l2, 3), q3n = d.q(l2, 3);
+            const bool ok0 = (dd0 << 1) < beta_2 && abs(p3 - p0) + abs(q0 - q3) < beta_3 && abs(p0 - q0) < tc25;
+            const bool ok1 = (dd1 << 1) < beta_2 && abs(p3n - p0n) + abs(q0n - q3n) < beta_3 && abs(p0n - q0n) < tc25;
+            strong = ok0 && ok1;
+        }
+        if (!strong)
+            len_p = len_q = 1;
+    }
+    const int kind = (len_p == 3 && len_q == 3) ? 2 : (len_q == 3) ? 1 : 0;
+    for (int l = 0; l < lines; l++) {
+        const int p3 = d.p(l, 3), p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
+        const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2), q3 = d.q(l, 3);
+        if (kind == 2) {
+            if (!no_p) {
+                d.sp(l, 0, clip3((p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc));
+                d.sp(l, 1, clip3((2 * p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3, p1 - tc, p1 + tc));
+                d.sp(l, 2, clip3((3 * p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc));
+            }
+            if (!no_q) {
+                d.sq(l, 0, clip3((p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc));
+                d.sq(l, 1, clip3((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc));
+                d.sq(l, 2, clip3((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc));
+            }
+        } else if (kind == 1) {
+            if (!no_p)
+                d.sp(l, 0, clip3((3 * p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc));
+            if (!no_q) {
+                d.sq(l, 0, clip3((2 * p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc));
+                d.sq(l, 1, clip3((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc));
+                d.sq(l, 2, clip3((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc));
+            }
+        } else {
+            const int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+            if (!no_p) d.sp(l, 0, clip_px<BD>(p0 + delta));
+            if (!no_q) d.sq(l, 0, clip_px<BD>(q0 - delta));
+        }
+    }
+}
+
+// One lane per segment; a job is one reference slot call (8 samples along the edge = 2 luma segments, or 2 / 4 chroma ones).
+template <int BD>
+__global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *__restrict__ jobs, int n_jobs)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t >> 2, seg = t & 3;
+    if (j >= n_jobs)
+        return;
+    const vvc355_deblock_job job = jobs[j];
+    const int lines = job.chroma ? (job.flag ? 2 : 4) : 4;
+    if (seg >= 8 / lines)
+        return;
+    const ptrdiff_t pxstride = job.stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    Dbk<BD> d;
+    d.xs = job.dir == 0 ? pxstride : 1;
+    d.ys = job.dir == 0 ? 1 : pxstride;
+    d.pix = (uint8_t *)job.pix + seg * lines * d.ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
+    if (job.chroma)
+        dbk_chroma_segment<BD>(d, lines, job.tc[seg], job.beta[seg], job.no_p[seg], job.no_q[seg], job.max_len_p[seg], job.max_len_q[seg]);
+    else
+        dbk_luma_segment<BD>(d, job.tc[seg], job.beta[seg], job.no_p[seg], job.no_q[seg], job.max_len_p[seg], job.max_len_q[seg], job.flag);
+}
+
+template <int BD>
+__global__ void ladf_kernel(const uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int *out)
+{
+    *out = (ld_px<BD>(pix, -xs) + ld_px<BD>(pix, -xs + 3 * ys) + ld_px<BD>(pix, 0) + ld_px<BD>(pix, 3 * ys)) >> 2;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+static void launch_sao(int bd, const vvc355_sao_job *jobs, int n, int max_w, int max_h, hipStream_t st)
+{
+    if (n <= 0) return;
+    const int gx = max(1, min(16, (max_w * max_h + 1023) / 1024));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_kernel<BD>), dim3(gx, n), dim3(256), 0, st, jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+static void launch_deblock(int bd, const vvc355_deblock_job *jobs, int n, hipStream_t st)
+{
+    if (n <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((deblock_kernel<BD>), dim3((n * 4 + 255) / 256), dim3(256), 0, st, jobs, n));
+    HIP_CHECK(hipGetLastError());
+}
+
+static void slot_deblock(int bd, int dir, int chroma, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+                         const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int flag)
+{
+    const int px = bd > 8 ? 2 : 1;
+    const int nseg = chroma ? (flag ? 4 : 2) : 2;
+    SlotCall call;
+    // samples across the edge: 8 on each side (luma long filters read P7/Q7); 8 along it
+    const Staged s = dir == 0 ? call.rect(pix, stride, 0, 8 * px, -8, 8, true, true)
+                              : call.rect(pix, stride, -8 * px, 8 * px, 0, 8, true, true);
+    vvc355_deblock_job job = {};
+    job.pix = (uint64_t)s.dev; job.stride = (int32_t)s.pitch;
+    job.dir = (uint8_t)dir; job.chroma = (uint8_t)chroma; job.flag = (uint8_t)flag;
+    for (int i = 0; i < nseg; i++) {
+        job.beta[i] = beta[i]; job.tc[i] = tc[i];
+        job.no_p[i] = no_p[i]; job.no_q[i] = no_q[i]; job.max_len_p[i] = max_len_p[i]; job.max_len_q[i] = max_len_q[i];
+    }
+    launch_deblock(bd, call.upload(&job, 1), 1, call.stream());
+}
+
+} // namespace vvc355
+
+using namespace vvc355;
+
+extern "C" {
+
+void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h)
+{
+    launch_sao(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
+}
+
+void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs)
+{
+    launch_deblock(bd, jobs_dev, n_jobs, (hipStream_t)stream);
+}
+
+void vvc355_lmcs_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs, int max_w, int max_h)
+{
+    if (n_jobs <= 0) return;
+    const int gx = max(1, min(16, (max_w * max_h + 1023) / 1024));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((lmcs_kernel<BD>), dim3(gx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_lmcs_filter(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height, const uint8_t *lut)
+{
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, true, true);
+    vvc355_blend_job job = {};
+    job.dst = (uint64_t)d.dev; job.dst_stride = (int32_t)d.pitch;
+    job.src0 = (uint64_t)call.linear(lut, (size_t)px << bd, true, false);
+    job.w = (int16_t)width; job.h = (int16_t)height;
+    vvc355_lmcs_batch(call.stream(), bd, call.upload(&job, 1), 1, width, height);
+}
+
+void vvc355_sao_band_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+                            const int16_t *sao_offset_val, int sao_left_class, int width, int height)
+{
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, 0, width * px, 0, height, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, false, true);
+    vvc355_sao_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev; job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.w = (int16_t)width; job.h = (int16_t)height; job.type = 1; job.band_position = (uint8_t)sao_left_class;
+    for (int k = 0; k < 5; k++) job.offset_val[k] = sao_offset_val[k];
+    launch_sao(bd, call.upload(&job, 1), 1, width, height, call.stream());
+}
+
+void vvc355_sao_edge_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride,
+                            const int16_t *sao_offset_val, int eo, int width, int height)
+{
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1;
+    const ptrdiff_t src_stride = 2 * VVC355_PB + 64;      // implicit: 2*MAX_PB_SIZE + AV_INPUT_BUFFER_PADDING_SIZE (vvcdsp.h:140)
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, -px, (width + 1) * px, -1, height + 1, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, false, true);
+    vvc355_sao_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev; job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.w = (int16_t)width; job.h = (int16_t)height; job.type = 2; job.eo = (uint8_t)eo;
+    for (int k = 0; k < 5; k++) job.offset_val[k] = sao_offset_val[k];
+    launch_sao(bd, call.upload(&job, 1), 1, width, height, call.stream());
+}
+
+void vvc355_sao_edge_restore(int bd, int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+                             const int16_t *offset_val, int eo_class, const int *borders, int width, int height,
+                             const uint8_t *vert_edge, const uint8_t *horiz_edge, const uint8_t *diag_edge)
+{
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    const Staged s = call.rect(src, src_stride, 0, width * px, 0, height, true, false);
+    const Staged d = call.rect(dst, dst_stride, 0, width * px, 0, height, true, true);
+    vvc355_sao_job job = {};
+    job.dst = (uint64_t)d.dev; job.src = (uint64_t)s.dev; job.dst_stride = (int32_t)d.pitch; job.src_stride = (int32_t)s.pitch;
+    job.w = (int16_t)width; job.h = (int16_t)height; job.type = 4; job.eo = (uint8_t)eo_class; job.restore = (uint8_t)!!variant;
+    for (int k = 0; k < 5; k++) job.offset_val[k] = offset_val[k];
+    for (int k = 0; k < 4; k++) { job.borders[k] = (uint8_t)!!borders[k]; job.diag_edge[k] = variant ? diag_edge[k] : 0; }
+    for (int k = 0; k < 2; k++) { job.vert_edge[k] = variant ? vert_edge[k] : 0; job.horiz_edge[k] = variant ? horiz_edge[k] : 0; }
+    launch_sao(bd, call.upload(&job, 1), 1, width, height, call.stream());
+}
+
+void vvc355_lf_filter_luma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+                           const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int hor_ctu_edge)
+{
+    slot_deblock(bd, dir, 0, pix, stride, beta, tc, no_p, no_q, max_len_p, max_len_q, hor_ctu_edge);
+}
+
+void vvc355_lf_filter_chroma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+                             const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int shift)
+{
+    slot_deblock(bd, dir, 1, pix, stride, beta, tc, no_p, no_q, max_len_p, max_len_q, shift);
+}
+
+int vvc355_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t stride)
+{
+    const int px = bd > 8 ? 2 : 1;
+    int result = 0;
+    {
+        SlotCall call;
+        const Staged s = dir == 0 ? call.rect(pix, stride, 0, 4 * px, -1, 1, true, false)
+                                  : call.rect(pix, stride, -px, px, 0, 4, true, false);
+        int *out = (int *)call.linear(&result, sizeof(int), false, true);
+        const ptrdiff_t ps = s.pitch / px;
+        const ptrdiff_t xs = dir == 0 ? ps : 1, ys = dir == 0 ? 1 : ps;
+        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((ladf_kernel<BD>), dim3(1), dim3(1), 0, call.stream(), (const uint8_t *)s.dev, xs, ys, out));
+        HIP_CHECK(hipGetLastError());
+    }
+    return result;
+}
+
+} // extern "C"

@@ -173,6 +173,60 @@ int  vvc355_sad(const int16_t *src0, const int16_t *src1, int dx, int dy, int bl
 void vvc355_dmvr(int bd, int vfrac, int hfrac, int16_t *dst, const uint8_t *src, ptrdiff_t src_stride, int height,
     intptr_t mx, intptr_t my, int width);
 
+/* ------------------------------------------------------------------ LMCS / SAO / deblock (loopfilter.hip) */
+
+/* One SAO rectangle (a CTB of one component).  type 1 = band (h2656_sao_template.c:24), 2 = edge (:50),
+ * 3 = edge + restore fused (what vvc_filter.c:290-293 chains: src = the pre-SAO plane itself, picture-border and
+ * slice/tile-edge samples handled per borders[] / *_edge[]), 4 = restore only (:81 / :131). */
+typedef struct vvc355_sao_job {
+    uint64_t dst;
+    uint64_t src;
+    int32_t  dst_stride, src_stride;      /* bytes */
+    int16_t  w, h;
+    int16_t  offset_val[5];               /* SAOParams.offset_val[c_idx] */
+    uint8_t  type, eo, band_position, restore;
+    uint8_t  borders[4];                  /* left, top, right, bottom picture borders */
+    uint8_t  vert_edge[2], horiz_edge[2], diag_edge[4];
+    uint8_t  pad_[2];
+} vvc355_sao_job;
+
+/* One deblocking call of the reference: 8 samples along an edge (2 luma segments of 4 lines; chroma 2 x 4 or,
+ * when subsampled along the edge, 4 x 2).  pix = DEVICE address of q0 of the first line; dir 0 = the [h] slot
+ * (horizontal edge), 1 = the [v] slot.  flag = hor_ctu_edge (luma) / shift (chroma). */
+typedef struct vvc355_deblock_job {
+    uint64_t pix;
+    int32_t  stride;                      /* bytes */
+    int32_t  beta[4], tc[4];
+    uint8_t  no_p[4], no_q[4], max_len_p[4], max_len_q[4];
+    uint8_t  dir, chroma, flag, pad_;
+} vvc355_deblock_job;
+
+void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h);
+/* all jobs of one launch must be independent (e.g. every vertical edge of a frame, then every horizontal edge) */
+void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs);
+/* blend_job: dst = luma rectangle (in place), src0 = LUT of 2^bd pixel-typed entries */
+void vvc355_lmcs_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs, int max_w, int max_h);
+
+/* VVCLMCSDSPContext.filter — vvcdsp.h:124, vvc_filter_template.c:25 */
+void vvc355_lmcs_filter(int bd, uint8_t *dst, ptrdiff_t dst_stride, int width, int height, const uint8_t *lut);
+/* VVCSAODSPContext.band_filter[*] — vvcdsp.h:138, h2656_sao_template.c:24 */
+void vvc355_sao_band_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+    const int16_t *sao_offset_val, int sao_left_class, int width, int height);
+/* .edge_filter[*] — vvcdsp.h:141, h2656_sao_template.c:50 (implicit source stride 2*128+64 bytes) */
+void vvc355_sao_edge_filter(int bd, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride,
+    const int16_t *sao_offset_val, int eo, int width, int height);
+/* .edge_restore[variant] — vvcdsp.h:143, h2656_sao_template.c:81,131; SAOParams flattened to
+ * offset_val = sao->offset_val[c_idx], eo_class = sao->eo_class[c_idx] (vvc_ctu.h:440) */
+void vvc355_sao_edge_restore(int bd, int variant, uint8_t *dst, const uint8_t *src, ptrdiff_t dst_stride, ptrdiff_t src_stride,
+    const int16_t *offset_val, int eo_class, const int *borders, int width, int height,
+    const uint8_t *vert_edge, const uint8_t *horiz_edge, const uint8_t *diag_edge);
+/* VVCLFDSPContext.filter_luma[dir] / filter_chroma[dir] / ladf_level[dir] — vvcdsp.h:128-133, vvc_filter_template.c:546,681,788 */
+void vvc355_lf_filter_luma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+    const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int hor_ctu_edge);
+void vvc355_lf_filter_chroma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, const int32_t *beta, const int32_t *tc,
+    const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int shift);
+int  vvc355_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t stride);
+
 #ifdef __cplusplus
 }
 #endif
