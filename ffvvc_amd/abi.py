@@ -54,6 +54,13 @@ SLOT_SIGNATURES = {
     "lf_filter_luma":     ("v", "iipqppppppi"),
     "lf_filter_chroma":   ("v", "iipqppppppi"),
     "lf_ladf_level":      ("i", "iipq"),
+    # ---- inverse transform / residual (no leading bd where the reference slot is bit-depth independent)
+    "itx":                  ("i", "iiiipzzqq"),
+    "inv_lfnst_1d":         ("v", "ppiiiii"),
+    "add_residual":         ("v", "ippiiq"),
+    "add_residual_joint":   ("v", "ippiiqii"),
+    "pred_residual_joint":  ("v", "piiii"),
+    "transform_bdpcm":      ("v", "piiii"),
 }
 
 RUNTIME_SIGNATURES = {
@@ -79,6 +86,7 @@ BATCH_SIGNATURES = {
     "sao_batch":        ("v", "pipiii"),
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
+    "itx_batch":        ("v", "pipi"),
 }
 
 
@@ -165,4 +173,14 @@ class DeblockJob(ctypes.Structure):
         ("no_p", ctypes.c_uint8 * 4), ("no_q", ctypes.c_uint8 * 4),
         ("max_len_p", ctypes.c_uint8 * 4), ("max_len_q", ctypes.c_uint8 * 4),
         ("dir", ctypes.c_uint8), ("chroma", ctypes.c_uint8), ("flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
+    ]
+
+
+class ItxJob(ctypes.Structure):
+    """Mirror of vvc355_itx_job."""
+    _fields_ = [
+        ("coeffs", ctypes.c_uint64), ("dst", ctypes.c_uint64), ("dst_stride", ctypes.c_int32),
+        ("trh", ctypes.c_uint8), ("trv", ctypes.c_uint8), ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8),
+        ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8), ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8),
+        ("store_coeffs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 3),
     ]

@@ -1,0 +1,289 @@
+// Inverse transform (DCT-2 / DST-7 / DCT-8, 1-D and 2-D, up to 64x64), LFNST, residual add and BDPCM kernels for gfx950.
+//
+// Reference behaviour: libavcodec/vvc/vvcdsp.c:67-195 (scale_clip, scale, itx_2d, itx_1d, the generator),
+// libavcodec/vvc/vvc_itx_1d.c:64-721 (nz gating of the DCT-2 butterflies, matrix_mul, ff_vvc_inv_lfnst_1d),
+// libavcodec/vvc/vvcdsp_template.c:32-100 (add_residual, joint variants, transform_bdpcm) and :142-159 (which entries exist).
+//
+// The reference's partial butterflies are wrapping int32 arithmetic, i.e. exactly a dot product with the transform matrix
+// over the inputs its nz gating keeps.  One workgroup owns one transform block: coefficients are staged in LDS, the column
+// pass spreads (column, output row) pairs over the lanes, then the row pass does the same for (row, output column).
+#include "common.hpp"
+#include "runtime.hpp"
+#include "../../include/vvc_mi355.h"
+
+namespace vvc355 {
+
+#define VVC355_TABLE(type, name, count) __device__ static const type d_tab_##name[count]
+#include "tables.inc"
+#undef VVC355_TABLE
+
+enum { TX_DCT2 = 0, TX_DST7 = 1, TX_DCT8 = 2 };
+
+__device__ __forceinline__ const int8_t *dxt_matrix(int type, int n)
+{
+    if (type == TX_DST7)
+        return n == 4 ? d_tab_dst7_4 : n == 8 ? d_tab_dst7_8 : n == 16 ? d_tab_dst7_16 : d_tab_dst7_32;
+    return n == 4 ? d_tab_dct8_4 : n == 8 ? d_tab_dct8_8 : n == 16 ? d_tab_dct8_16 : d_tab_dct8_32;
+}
+
+// Number of leading inputs a 1-D transform of size n reads for a given nz (vvc_itx_1d.c:64-67,:498,:659):
+// DCT-2 gates inputs in groups {0,1},{2,3},{4..7},{8..15},{16..31} and never reads inputs >= 32 of the 64-point transform;
+// DST-7 / DCT-8 read exactly nz (<= 16) inputs.
+__device__ __forceinline__ int inputs_used(int type, int n, int nz)
+{
+    if (type != TX_DCT2)
+        return nz;
+    int used = 2;
+    while (used < nz)
+        used <<= 1;                  // k takes part iff k < 2 or nz > 2^floor(log2 k)  <=>  k < used
+    used = min(used, n);
+    return n == 64 ? min(used, 32) : used;
+}
+
+// output i of an n-point inverse transform of `cnt` inputs in[0], in[step], ...
+__device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in, int step, int cnt, const int8_t *cos_lds)
+{
+    unsigned acc = 0;
+    if (type == TX_DCT2) {
+        const int ang = (2 * i + 1) * (64 / n);
+        for (int k = 0; k < cnt; k++)
+            acc += (unsigned)in[k * step] * (unsigned)(int)cos_lds[(ang * k) & 255];
+    } else {
+        const int8_t *m = dxt_matrix(type, n) + i;
+        for (int k = 0; k < cnt; k++)
+            acc += (unsigned)in[k * step] * (unsigned)(int)m[k * n];
+    }
+    return (int)acc;
+}
+
+template <int BD>
+__global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs)
+{
+    __shared__ int buf[64 * 64];
+    __shared__ int tmp[64 * 64];
+    __shared__ int8_t cos_lds[256];
+    const vvc355_itx_job job = jobs[blockIdx.x];
+    const int w = 1 << job.log2_w, h = 1 << job.log2_h, n = w * h;
+    const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
+    int *coeffs = (int *)job.coeffs;
+    const int tid = threadIdx.x;
+
+    cos_lds[tid] = d_tab_dct2_cos[tid];
+    for (int i = tid; i < n; i += 256)
+        buf[i] = coeffs[i];
+    __syncthreads();
+
+    const bool dc_only = job.trh == TX_DCT2 && job.trv == TX_DCT2 && nzw == 1 && nzh == 1;
+    int sh_final;
+    if (w > 1 && h > 1) {
+        const int sh1 = 7;
+        sh_final = 5 + range - bd;
+        if (w == h && dc_only) {
+            const int t = (buf[0] * 64 + (1 << (sh1 - 1))) >> sh1;
+            const int dc = (t * 64 + (1 << (sh_final - 1))) >> sh_final;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256)
+                buf[i] = dc;
+            sh_final = -1;
+        } else {
+            // column pass on columns < nzw (vertical type, size h), then scale_clip; other columns become zero
+            const int cnt = inputs_used(job.trv, h, nzh);
+            for (int o = tid; o < n; o += 256) {
+                const int y = o / w, x = o - y * w;
+                int v = 0;
+                if (x < nzw) {
+                    v = inv_tx_out(job.trv, h, y, buf + x, w, cnt, cos_lds);
+                    v = clip_intp2((v + (1 << (sh1 - 1))) >> sh1, range);
+                }
+                tmp[o] = v;
+            }
+            __syncthreads();
+            // row pass (horizontal type, size w) with nz = nzw
+            const int cnt2 = inputs_used(job.trh, w, nzw);
+            for (int o = tid; o < n; o += 256) {
+                const int y = o / w, x = o - y * w;
+                buf[o] = inv_tx_out(job.trh, w, x, tmp + y * w, 1, cnt2, cos_lds);
+            }
+        }
+    } else {
+        sh_final = 6 + range - bd;
+        if (dc_only) {
+            const int dc = (buf[0] * 64 + (1 << (sh_final - 1))) >> sh_final;
+            __syncthreads();
+            for (int i = tid; i < n; i += 256)
+                buf[i] = dc;
+            sh_final = -1;
+        } else {
+            const int type = w > 1 ? job.trh : job.trv, nz = w > 1 ? nzw : nzh;
+            const int cnt = inputs_used(type, n, nz);
+            for (int o = tid; o < n; o += 256)
+                tmp[o] = inv_tx_out(type, n, o, buf, 1, cnt, cos_lds);
+            __syncthreads();
+            for (int o = tid; o < n; o += 256)
+                buf[o] = tmp[o];
+        }
+    }
+    __syncthreads();
+    // final scale, then either store residuals in place (slot semantics) and/or add them to the prediction
+    uint8_t *dst = (uint8_t *)job.dst;
+    for (int o = tid; o < n; o += 256) {
+        const int r = sh_final < 0 ? buf[o] : (buf[o] + (1 << (sh_final - 1))) >> sh_final;
+        if (job.store_coeffs)
+            coeffs[o] = r;
+        if (dst) {
+            const int y = o / w, x = o - y * w;
+            uint8_t *row = dst + (ptrdiff_t)y * job.dst_stride;
+            st_px<BD>(row, x, clip_px<BD>(ld_px<BD>(row, x) + r));
+        }
+    }
+}
+
+// add_residual / add_residual_joint / pred_residual_joint (vvcdsp_template.c:32,48,65); job.src0 = int residuals,
+// mode 0 add, 1 joint add (w0 = c_sign, denom = shift), 2 joint in place on the int buffer (dst unused)
+template <int BD>
+__global__ __launch_bounds__(256) void residual_kernel(const vvc355_blend_job *__restrict__ jobs)
+{
+    const vvc355_blend_job job = jobs[blockIdx.y];
+    int *res = (int *)job.src0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
+        int r = res[i];
+        if (job.mode)
+            r = (r * job.w0) >> job.denom;
+        if (job.mode == 2) {
+            res[i] = r;
+            continue;
+        }
+        const int y = i / job.w, x = i - y * job.w;
+        uint8_t *row = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
+        st_px<BD>(row, x, clip_px<BD>(ld_px<BD>(row, x) + r));
+    }
+}
+
+// transform_bdpcm (:76): one lane per column (vertical) or row; job.dst = int coeffs, mode = vertical, denom = range
+__global__ __launch_bounds__(128) void bdpcm_kernel(const vvc355_blend_job *__restrict__ jobs)
+{
+    const vvc355_blend_job job = jobs[blockIdx.x];
+    int *c = (int *)job.dst;
+    const int w = job.w, h = job.h, range = job.denom, t = threadIdx.x;
+    if (job.mode) {
+        if (t < w)
+            for (int y = 1; y < h; y++)
+                c[y * w + t] = clip_intp2(c[y * w + t] + c[(y - 1) * w + t], range);
+    } else {
+        if (t < h)
+            for (int x = 1; x < w; x++)
+                c[t * w + x] = clip_intp2(c[t * w + x] + c[t * w + x - 1], range);
+    }
+}
+
+// ff_vvc_inv_lfnst_1d (vvc_itx_1d.c:708): v[j] = clip((sum_i u[i] * M[i][j] + 64) >> 7); one lane per output
+__global__ __launch_bounds__(64) void lfnst_kernel(int *v, const int *u, int nz, int n_tr_s, int set, int idx, int range)
+{
+    const int j = threadIdx.x;
+    if (j >= n_tr_s)
+        return;
+    const int8_t *m = n_tr_s > 16 ? d_tab_lfnst_8x8 + (set * 2 + idx - 1) * 16 * 48 : d_tab_lfnst_4x4 + (set * 2 + idx - 1) * 16 * 16;
+    unsigned t = 0;
+    for (int i = 0; i < nz; i++)
+        t += (unsigned)u[i] * (unsigned)(int)m[i * n_tr_s + j];
+    v[j] = clip_intp2(((int)t + 64) >> 7, range);
+}
+
+static bool itx_entry_exists(int trh, int trv, int lw, int lh)
+{
+    if (lw < 0 || lh < 0 || lw > 6 || lh > 6 || trh < 0 || trh > 2 || trv < 0 || trv > 2 || (lw == 0 && lh == 0))
+        return false;
+    if (lh == 0) return trv == TX_DCT2 && (lw == 4 || lw == 5 || (lw == 6 && trh == TX_DCT2));
+    if (lw == 0) return trh == TX_DCT2 && (lh == 4 || lh == 5 || (lh == 6 && trv == TX_DCT2));
+    if (trh != TX_DCT2 && (lw < 2 || lw > 5)) return false;
+    if (trv != TX_DCT2 && (lh < 2 || lh > 5)) return false;
+    return true;
+}
+
+} // namespace vvc355
+
+using namespace vvc355;
+
+extern "C" {
+extern const uint8_t vvc355_tab_lfnst_tr_set_index[95];
+
+void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs)
+{
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((itx_kernel<BD>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    HIP_CHECK(hipGetLastError());
+}
+
+int vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
+               intptr_t log2_transform_range, intptr_t bit_depth)
+{
+    if (!itx_entry_exists(trh, trv, log2_w, log2_h))
+        return -1;
+    const int n = 1 << (log2_w + log2_h);
+    SlotCall call;
+    vvc355_itx_job job = {};
+    job.coeffs = (uint64_t)call.linear(coeffs, (size_t)n * sizeof(int), true, true);
+    job.trh = (uint8_t)trh; job.trv = (uint8_t)trv; job.log2_w = (uint8_t)log2_w; job.log2_h = (uint8_t)log2_h;
+    job.nzw = (uint8_t)nzw; job.nzh = (uint8_t)nzh; job.range = (uint8_t)log2_transform_range; job.bd = (uint8_t)bit_depth;
+    job.store_coeffs = 1;
+    vvc355_itx_batch(call.stream(), (int)bit_depth == 8 || (int)bit_depth == 10 || (int)bit_depth == 12 ? (int)bit_depth : 10,
+                     call.upload(&job, 1), 1);
+    return 0;
+}
+
+void vvc355_inv_lfnst_1d(int *v, const int *u, int no_zero_size, int n_tr_s, int pred_mode_intra, int lfnst_idx,
+                         int log2_transform_range)
+{
+    const int set = pred_mode_intra < 0 ? 1 : vvc355_tab_lfnst_tr_set_index[pred_mode_intra];
+    SlotCall call;
+    int *dv = (int *)call.linear(v, (size_t)n_tr_s * sizeof(int), false, true);
+    const int *du = (const int *)call.linear(u, (size_t)no_zero_size * sizeof(int), true, false);
+    hipLaunchKernelGGL(lfnst_kernel, dim3(1), dim3(64), 0, call.stream(), dv, du, no_zero_size, n_tr_s, set, lfnst_idx, log2_transform_range);
+    HIP_CHECK(hipGetLastError());
+}
+
+static void slot_residual(int bd, int mode, uint8_t *dst, int *res, int width, int height, ptrdiff_t stride, int c_sign, int shift)
+{
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1;
+    SlotCall call;
+    vvc355_blend_job job = {};
+    if (mode != 2) {
+        const Staged d = call.rect(dst, stride, 0, width * px, 0, height, true, true);
+        job.dst = (uint64_t)d.dev; job.dst_stride = (int32_t)d.pitch;
+    }
+    job.src0 = (uint64_t)call.linear(res, (size_t)width * height * sizeof(int), true, mode == 2);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.mode = (int16_t)mode; job.w0 = (int16_t)c_sign; job.denom = (int16_t)shift;
+    const vvc355_blend_job *jd = call.upload(&job, 1);
+    const int gx = (width * height + 1023) / 1024;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((residual_kernel<BD>), dim3(gx, 1), dim3(256), 0, call.stream(), jd));
+    HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_add_residual(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride)
+{
+    slot_residual(bd, 0, dst, const_cast<int *>(res), width, height, stride, 0, 0);
+}
+
+void vvc355_add_residual_joint(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride, int c_sign, int shift)
+{
+    slot_residual(bd, 1, dst, const_cast<int *>(res), width, height, stride, c_sign, shift);
+}
+
+void vvc355_pred_residual_joint(int *buf, int width, int height, int c_sign, int shift)
+{
+    slot_residual(10, 2, nullptr, buf, width, height, 0, c_sign, shift);
+}
+
+void vvc355_transform_bdpcm(int *coeffs, int width, int height, int vertical, int log2_transform_range)
+{
+    if (width <= 0 || height <= 0 || width > 128 || height > 128) return;
+    SlotCall call;
+    vvc355_blend_job job = {};
+    job.dst = (uint64_t)call.linear(coeffs, (size_t)width * height * sizeof(int), true, true);
+    job.w = (int16_t)width; job.h = (int16_t)height; job.mode = (int16_t)!!vertical; job.denom = (int16_t)log2_transform_range;
+    hipLaunchKernelGGL(bdpcm_kernel, dim3(1), dim3(128), 0, call.stream(), call.upload(&job, 1));
+    HIP_CHECK(hipGetLastError());
+}
+
+} // extern "C"

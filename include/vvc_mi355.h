@@ -227,6 +227,36 @@ void vvc355_lf_filter_chroma(int bd, int dir, uint8_t *pix, ptrdiff_t stride, co
     const uint8_t *no_p, const uint8_t *no_q, const uint8_t *max_len_p, const uint8_t *max_len_q, int shift);
 int  vvc355_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t stride);
 
+/* ------------------------------------------------------------------ inverse transform + residual (itx.hip) */
+
+enum { VVC355_DCT2 = 0, VVC355_DST7 = 1, VVC355_DCT8 = 2 };     /* enum TxType, vvcdsp.h:30 */
+
+/* One transform block.  coeffs: DEVICE int32[w*h], row-major (stride w), transformed in place when store_coeffs != 0.
+ * dst != 0 additionally adds the residual to the w x h pixel rectangle at dst (itx + add_residual fused, what
+ * vvc_intra.c:464-472 chains).  bd here is the bit_depth ARGUMENT of the slot (it sets the second-stage shift). */
+typedef struct vvc355_itx_job {
+    uint64_t coeffs;
+    uint64_t dst;
+    int32_t  dst_stride;
+    uint8_t  trh, trv, log2_w, log2_h, nzw, nzh, range, bd;
+    uint8_t  store_coeffs, pad_[3];
+} vvc355_itx_job;
+
+void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs);
+
+/* VVCItxDSPContext.itx[trh][trv][log2 w][log2 h] — vvcdsp.h:118, vvcdsp.c:94-195.  Returns -1 (nothing done) for a
+ * combination the reference table leaves NULL (vvcdsp_template.c:142-159), else 0. */
+int  vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
+    intptr_t log2_transform_range, intptr_t bit_depth);
+/* ff_vvc_inv_lfnst_1d — vvc_itx_1d.h, vvc_itx_1d.c:708 (called by vvc_intra.c:65-127, not a table slot) */
+void vvc355_inv_lfnst_1d(int *v, const int *u, int no_zero_size, int n_tr_s, int pred_mode_intra, int lfnst_idx,
+    int log2_transform_range);
+/* .add_residual / .add_residual_joint / .pred_residual_joint / .transform_bdpcm — vvcdsp.h:114-120, vvcdsp_template.c:32-100 */
+void vvc355_add_residual(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride);
+void vvc355_add_residual_joint(int bd, uint8_t *dst, const int *res, int width, int height, ptrdiff_t stride, int c_sign, int shift);
+void vvc355_pred_residual_joint(int *buf, int width, int height, int c_sign, int shift);
+void vvc355_transform_bdpcm(int *coeffs, int width, int height, int vertical, int log2_transform_range);
+
 #ifdef __cplusplus
 }
 #endif

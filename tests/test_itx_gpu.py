@@ -1,0 +1,80 @@
+"""GPU parity: inverse transform / LFNST / residual slots through the C ABI vs the CPU oracle, bit-exact.
+Mirrors tests/checkasm/vvc_itx.c:25-36,48-51,58-93: every (trh, trv, w, h) the table holds, random nzw/nzh inside the
+zero-out limits (32 for DCT-2, 16 for DST-7/DCT-8), coefficients clipped to log2_transform_range, zeros elsewhere."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_pixels
+
+pytestmark = pytest.mark.gpu
+DCT2, DST7, DCT8 = 0, 1, 2
+
+
+def coeff_block(rng, w, h, nzw, nzh, rng_bits):
+    c = np.zeros((h, w), np.int32)
+    c[:nzh, :nzw] = rng.integers(-(1 << rng_bits), 1 << rng_bits, size=(nzh, nzw))
+    return c
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_itx_all_entries(dev, orc, bd):
+    rng = np.random.default_rng(0x5EED0400 + bd)
+    n_valid = 0
+    for rng_bits in (15, max(15, min(20, bd + 6))):
+        for lw in range(7):
+            for lh in range(7):
+                w, h = 1 << lw, 1 << lh
+                for trh in (DCT2, DST7, DCT8):
+                    for trv in (DCT2, DST7, DCT8):
+                        for rep in range(3):
+                            nzw = int(rng.integers(1, min(32 if trh == DCT2 else 16, w) + 1))
+                            nzh = int(rng.integers(1, min(32 if trv == DCT2 else 16, h) + 1))
+                            if rep == 2:
+                                nzw = nzh = 1          # DC-only shortcut
+                            c0 = coeff_block(rng, w, h, nzw, nzh, rng_bits)
+                            c1 = c0.copy()
+                            r0 = orc.orc_itx(trh, trv, lw, lh, P(c0), nzw, nzh, rng_bits, bd)
+                            r1 = dev.vvc355_itx(trh, trv, lw, lh, P(c1), nzw, nzh, rng_bits, bd)
+                            assert r0 == r1
+                            if r0 == 0:
+                                n_valid += 1
+                                assert np.array_equal(c0, c1), f"itx trh={trh} trv={trv} {w}x{h} nz=({nzw},{nzh}) bd={bd} range={rng_bits}"
+    # 2-D: 5x5 sizes x 9 type pairs (4..32) + DCT2-only rows/cols for 2 and 64; 1-D: 16, 32 (3 types) and 64 (DCT2), both ways
+    assert n_valid > 500
+
+
+def test_lfnst(dev, orc):
+    rng = np.random.default_rng(0x5EED0410)
+    for n_tr_s, nz in ((16, 8), (16, 16), (48, 8), (48, 16)):
+        for mode in (-1, 0, 1, 17, 34, 50, 66, 80, 94):
+            for idx in (1, 2):
+                u = rng.integers(-(1 << 15), 1 << 15, size=16).astype(np.int32)
+                v0 = np.zeros(48, np.int32); v1 = np.zeros(48, np.int32)
+                orc.orc_inv_lfnst_1d(P(v0), P(u), nz, n_tr_s, mode, idx, 15)
+                dev.vvc355_inv_lfnst_1d(P(v1), P(u), nz, n_tr_s, mode, idx, 15)
+                assert np.array_equal(v0, v1)
+                assert np.any(v0 != 0)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_residual_and_bdpcm(dev, orc, bd):
+    rng = np.random.default_rng(0x5EED0420 + bd)
+    for (w, h) in [(4, 4), (8, 2), (2, 8), (32, 32), (64, 64), (64, 16), (1, 16), (16, 1)]:
+        res = rng.integers(-(1 << (bd + 1)), 1 << (bd + 1), size=(h, w)).astype(np.int32)
+        pred = rand_pixels(rng, (h + 2, w + 8), bd)
+        c_sign, shift = int(rng.choice([-1, 1])), int(rng.integers(0, 3))
+        outs = []
+        for lib, pre in ((orc, "orc_"), (dev, "vvc355_")):
+            ps = pred.itemsize
+            d0 = pred.copy()
+            getattr(lib, pre + "add_residual")(bd, P(d0, d0.shape[1] + 4), P(res), w, h, d0.shape[1] * ps)
+            d1 = pred.copy()
+            getattr(lib, pre + "add_residual_joint")(bd, P(d1, d1.shape[1] + 4), P(res), w, h, d1.shape[1] * ps, c_sign, shift)
+            b = res.copy()
+            getattr(lib, pre + "pred_residual_joint")(P(b), w, h, c_sign, shift)
+            bp = [res.copy(), res.copy()]
+            for vertical in (0, 1):
+                getattr(lib, pre + "transform_bdpcm")(P(bp[vertical]), w, h, vertical, 15)
+            outs.append((d0, d1, b, bp[0], bp[1]))
+        for i, (x, y) in enumerate(zip(*outs)):
+            assert np.array_equal(x, y), f"residual output {i} {w}x{h} bd={bd}"
