@@ -61,6 +61,15 @@ SLOT_SIGNATURES = {
     "add_residual_joint":   ("v", "ippiiqii"),
     "pred_residual_joint":  ("v", "piiii"),
     "transform_bdpcm":      ("v", "piiii"),
+    # ---- intra (leaf predictors: stride in PIXELS)
+    "pred_planar":        ("v", "ipppiiq"),
+    "pred_dc":            ("v", "ipppiiq"),
+    "pred_v":             ("v", "ippiiq"),
+    "pred_h":             ("v", "ippiiq"),
+    "pred_angular_v":     ("v", "ipppiiqiiiii"),
+    "pred_angular_h":     ("v", "ipppiiqiiiii"),
+    "pred_mip":           ("v", "ipppiiqii"),
+    "intra_pred_flat":    ("v", "ip"),
 }
 
 RUNTIME_SIGNATURES = {
@@ -87,6 +96,7 @@ BATCH_SIGNATURES = {
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipi"),
+    "intra_pred_batch": ("v", "pipi"),
 }
 
 
@@ -183,4 +193,18 @@ class ItxJob(ctypes.Structure):
         ("trh", ctypes.c_uint8), ("trv", ctypes.c_uint8), ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8),
         ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8), ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8),
         ("store_coeffs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 3),
+    ]
+
+
+class IntraJob(ctypes.Structure):
+    """Mirror of vvc355_intra_job (and of the oracle's orc_intra_job)."""
+    _fields_ = [
+        ("plane", ctypes.c_uint64), ("stride", ctypes.c_int32),
+        ("x", ctypes.c_int16), ("y", ctypes.c_int16), ("w", ctypes.c_int16), ("h", ctypes.c_int16),
+        ("mode", ctypes.c_int16), ("cb_width", ctypes.c_int16), ("cb_height", ctypes.c_int16),
+        ("left_avail", ctypes.c_int16), ("top_avail", ctypes.c_int16),
+        ("plane_w", ctypes.c_int16), ("plane_h", ctypes.c_int16),
+        ("c_idx", ctypes.c_uint8), ("ref_idx", ctypes.c_uint8), ("is_mip", ctypes.c_uint8), ("mip_mode", ctypes.c_uint8),
+        ("mip_transposed", ctypes.c_uint8), ("isp_split", ctypes.c_uint8), ("bdpcm_flag", ctypes.c_uint8),
+        ("cand_up_left", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6),
     ]

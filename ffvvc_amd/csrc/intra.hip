@@ -1,0 +1,508 @@
+// Intra-prediction kernels for gfx950: planar / DC / vertical / horizontal / angular (4-tap fC/fG luma, 2-tap chroma,
+// angular PDPC) / MIP leaf predictors, and the whole intra_pred slot (reference-sample preparation, [1 2 1] smoothing,
+// projected side references, predictor dispatch, planar/DC/V/H PDPC) with the decoder context flattened into a job.
+//
+// Reference behaviour: libavcodec/vvc/vvc_intra_template.c:450-1001 and the helpers in libavcodec/vvc/vvc_intra.c:529-690.
+// Leaf predictors keep the reference's convention that `stride` counts PIXELS (POS(), vvc_intra_template.c:27).
+//
+// One workgroup per block: reference samples live in LDS as uint16 with the reference's origin offset (MAX_TB_SIZE + 3),
+// lanes sweep the block row-major so that every row store is contiguous.
+#include "common.hpp"
+#include "runtime.hpp"
+#include "../../include/vvc_mi355.h"
+
+namespace vvc355 {
+
+#define VVC355_TABLE(type, name, count) __device__ static const type i_tab_##name[count]
+#include "tables.inc"
+#undef VVC355_TABLE
+
+static constexpr int kEdgeOrg = 64 + 3;          // MAX_TB_SIZE + 3
+static constexpr int kEdgeLen = 6 * 64 + 5;
+
+// ------------------------------------------------------------------------------------------------ mode helpers (host + device)
+
+__host__ __device__ inline int intra_pred_angle(int mode)
+{
+    const int angles[31] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29,
+                             32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512 };
+    const int idx = mode > 34 ? mode - 50 : mode > 0 ? 18 - mode : 16 - mode;
+    return idx < 0 ? -angles[-idx] : angles[idx];
+}
+// round(16384 / angle): the reference rounds a float quotient (vvc_intra.c:683-690); no quotient of the 30 table angles is
+// within float error of a half, so the integer form is exact (tests/test_oracle_cpu.py checks all of them)
+__host__ __device__ inline int intra_inv_angle(int angle)
+{
+    const int a = angle < 0 ? -angle : angle;
+    const int r = (16384 + a / 2) / a;
+    return angle < 0 ? -r : r;
+}
+__host__ __device__ inline int ilog2i(int v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+__host__ __device__ inline int intra_nscale(int w, int h, int mode)
+{
+    if (mode == 0 || mode == 1 || mode == 18 || mode == 50)
+        return (ilog2i(w) + ilog2i(h) - 2) >> 2;
+    const int inv = intra_inv_angle(intra_pred_angle(mode));
+    const int side = mode >= 50 ? h : w;
+    const int v = ilog2i(side) - ilog2i(3 * inv - 2) + 8;
+    return v < 2 ? v : 2;
+}
+__host__ __device__ inline int intra_need_pdpc(int w, int h, int bdpcm_flag, int mode, int ref_idx)
+{
+    if (w >= 4 && h >= 4 && !ref_idx && !bdpcm_flag) {
+        if (mode == 0 || mode == 1 || mode == 18 || mode == 50) return 1;
+        if (mode > 18 && mode < 50) return 0;
+        return intra_nscale(w, h, mode) >= 0;
+    }
+    return 0;
+}
+__host__ __device__ inline bool ref_filter_mode(int mode)
+{
+    return mode == -14 || mode == -12 || mode == -10 || mode == -6 || mode == 0 || mode == 2 || mode == 34 ||
+           mode == 66 || mode == 72 || mode == 76 || mode == 78 || mode == 80;
+}
+
+// reference-sample accessors: pixel-typed global arrays (leaf slots) or uint16 LDS arrays (flattened intra_pred)
+template <int BD> struct GRef {
+    const uint8_t *p;
+    __device__ __forceinline__ int operator()(int i) const { return ld_px<BD>(p, i); }
+};
+struct LRef {
+    const uint16_t *p;
+    __device__ __forceinline__ int operator()(int i) const { return p[i]; }
+};
+
+// ------------------------------------------------------------------------------------------------ leaf predictors (whole workgroup)
+
+template <int BD, typename R>
+__device__ void pred_planar(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h)
+{
+    const int lw = ilog2i(w), lh = ilog2i(h);
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        const int pv = ((h - 1 - y) * top(x) + (y + 1) * left(h)) << lw;
+        const int ph = ((w - 1 - x) * left(y) + (x + 1) * top(w)) << lh;
+        st_px<BD>(src, x + stride * y, (pv + ph + w * h) >> (lw + lh + 1));
+    }
+}
+
+template <int BD, typename R>
+__device__ void pred_dc(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int *scratch)
+{
+    if (threadIdx.x == 0) {
+        const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
+        int sum = 0;
+        if (w >= h) for (int i = 0; i < w; i++) sum += top(i);
+        if (w <= h) for (int i = 0; i < h; i++) sum += left(i);
+        *scratch = (sum + (int)(offset >> 1)) >> ilog2i((int)offset);
+    }
+    __syncthreads();
+    const int dc = *scratch, w4 = (w + 3) & ~3;          // stores cover whole groups of 4 (:856)
+    for (int i = threadIdx.x; i < w4 * h; i += blockDim.x) {
+        const int y = i / w4, x = i - y * w4;
+        st_px<BD>(src, x + stride * y, dc);
+    }
+}
+
+template <int BD, typename R>
+__device__ void pred_vh(uint8_t *src, ptrdiff_t stride, R ref, int w, int h, bool vertical)
+{
+    const int ww = vertical ? w : (w + 3) & ~3;           // pred_h stores whole groups of 4 (:885)
+    for (int i = threadIdx.x; i < ww * h; i += blockDim.x) {
+        const int y = i / ww, x = i - y * ww;
+        st_px<BD>(src, x + stride * y, vertical ? ref(x) : ref(y));
+    }
+}
+
+template <int BD, typename R>
+__device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx, int filter_flag)
+{
+    if (!fact && (c_idx || !filter_flag))
+        return ref(i + 1);
+    if (!c_idx) {
+        const int8_t *f = i_tab_intra_luma_filter + (filter_flag * 32 + fact) * 4;
+        return clip_px<BD>((ref(i) * f[0] + ref(i + 1) * f[1] + ref(i + 2) * f[2] + ref(i + 3) * f[3] + 32) >> 6);
+    }
+    return ((32 - fact) * ref(i + 1) + fact * ref(i + 2) + 16) >> 5;
+}
+
+template <int BD, typename R>
+__device__ void pred_angular(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, bool vertical,
+                             int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
+{
+    const int angle = intra_pred_angle(mode);
+    int inv = 0, nscale = 0;
+    if (need_pdpc) {
+        inv = intra_inv_angle(angle);
+        nscale = intra_nscale(w, h, mode);
+    }
+    const int base = -(1 + ref_idx);
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        const int along = vertical ? x : y, across = vertical ? y : x;
+        const int pos = (1 + ref_idx + across) * angle;
+        const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
+        int pred = vertical ? angular_sample<BD>(top, base + along + idx, fact, c_idx, filter_flag)
+                            : angular_sample<BD>(left, base + along + idx, fact, c_idx, filter_flag);
+        if (need_pdpc) {
+            if (vertical) {
+                if (x < min(w, 3 << nscale)) {
+                    const int l = left(y + ((256 + (x + 1) * inv) >> 9));
+                    pred = clip_px<BD>(pred + (((l - pred) * (32 >> ((x << 1) >> nscale)) + 32) >> 6));
+                }
+            } else if (y < (3 << nscale)) {
+                const int t = top(x + ((256 + (y + 1) * inv) >> 9));
+                pred = clip_px<BD>(pred + (((t - pred) * (32 >> min(31, (y * 2) >> nscale)) + 32) >> 6));
+            }
+        }
+        st_px<BD>(src, x + stride * y, pred);
+    }
+}
+
+// MIP (:708-824).  `red` = 16 ints of LDS scratch.
+template <int BD, typename R>
+__device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
+{
+    const int size_id = (w == 4 && h == 4) ? 0 : ((w == 4 || h == 4) || (w == 8 && h == 8)) ? 1 : 2;
+    const int bsize = size_id == 0 ? 2 : 4, psize = size_id == 2 ? 8 : 4;
+    const int in_size = 2 * bsize - (size_id == 2);
+    const uint8_t *matrix = size_id == 0 ? i_tab_mip_matrix_4x4 + mode_id * 16 * 4
+                          : size_id == 1 ? i_tab_mip_matrix_8x8 + mode_id * 16 * 8
+                                         : i_tab_mip_matrix_16x16 + mode_id * 64 * 7;
+    const int up_h = w / psize, up_v = h / psize;
+    __syncthreads();
+    if (threadIdx.x < 2 * bsize) {
+        // boundary down-sampling: first bsize entries from the top row (left column when transposed), then the other side
+        const int k = threadIdx.x, second = k >= bsize, from_top = second == (transposed != 0);
+        const int len = from_top ? w : h, per = len / bsize, i0 = (k - second * bsize) * per;
+        int s = 0;
+        for (int j = 0; j < per; j++)
+            s += from_top ? top(i0 + j) : left(i0 + j);
+        red[k] = per == 1 ? s : (s + (per >> 1)) >> ilog2i(per);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t0 = red[0];
+        int ow, off = 1;
+        if (size_id != 2) { off = 0; ow = (1 << (BD - 1)) - t0; }
+        else ow = red[1] - t0;
+        red[0] = ow;
+        for (int i = 1; i < in_size; i++) { red[i] = red[i + off] - t0; ow += red[i]; }
+        red[14] = 32 - 32 * ow;
+        red[15] = t0;
+    }
+    __syncthreads();
+    if (threadIdx.x < psize * psize) {
+        const int y = threadIdx.x / psize, x = threadIdx.x - y * psize;
+        int p = 0;
+        for (int i = 0; i < in_size; i++)
+            p += red[i] * matrix[(y * psize + x) * in_size + i];
+        p = clip3(((p + red[14]) >> 6) + red[15], 0, (1 << BD) - 1);
+        const int cx = transposed ? y : x, cy = transposed ? x : y;
+        st_px<BD>(src, (up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
+    }
+    __syncthreads();
+    if (up_h > 1 && threadIdx.x < psize) {            // one lane per row that holds reduced samples
+        const int row = up_v - 1 + threadIdx.x * up_v;
+        int before = left(row);
+        for (int j = 0; j < psize; j++) {
+            const int after = ld_px<BD>(src, (j + 1) * up_h - 1 + stride * row);
+            for (int k = 1; k < up_h; k++)
+                st_px<BD>(src, j * up_h + k - 1 + stride * row, ((up_h - k) * before + k * after + up_h / 2) / up_h);
+            before = after;
+        }
+    }
+    __syncthreads();
+    if (up_v > 1 && threadIdx.x < w) {                // one lane per column
+        const int x = threadIdx.x;
+        int before = top(x);
+        for (int j = 0; j < psize; j++) {
+            const int after = ld_px<BD>(src, x + stride * ((j + 1) * up_v - 1));
+            for (int k = 1; k < up_v; k++)
+                st_px<BD>(src, x + stride * (j * up_v + k - 1), ((up_v - k) * before + k * after + up_v / 2) / up_v);
+            before = after;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ leaf slot kernel
+
+// kind: 0 planar, 1 dc, 2 v, 3 h, 4 angular_v, 5 angular_h, 6 mip; one workgroup, job in kernel arguments
+struct LeafArgs {
+    uint8_t *src; const uint8_t *top, *left;
+    int stride, w, h, kind, c_idx, mode, ref_idx, filter_flag, need_pdpc, mip_mode, mip_transposed;
+};
+
+template <int BD>
+__global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
+{
+    __shared__ int scratch[16];
+    GRef<BD> top{ a.top }, left{ a.left };
+    switch (a.kind) {
+    case 0: pred_planar<BD>(a.src, a.stride, top, left, a.w, a.h); break;
+    case 1: pred_dc<BD>(a.src, a.stride, top, left, a.w, a.h, scratch); break;
+    case 2: pred_vh<BD>(a.src, a.stride, top, a.w, a.h, true); break;
+    case 3: pred_vh<BD>(a.src, a.stride, left, a.w, a.h, false); break;
+    case 4: pred_angular<BD>(a.src, a.stride, top, left, a.w, a.h, true, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    case 5: pred_angular<BD>(a.src, a.stride, top, left, a.w, a.h, false, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    default: pred_mip<BD>(a.src, a.stride, top, left, a.w, a.h, a.mip_mode, a.mip_transposed, scratch); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ flattened intra_pred
+
+// vvc_intra_template.c:467-592 (edge preparation) + :595-683 (dispatch, PDPC); one workgroup per job.
+template <int BD>
+__global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs)
+{
+    __shared__ uint16_t arr[4][kEdgeLen];
+    __shared__ int scratch[16];
+    const vvc355_intra_job j = jobs[blockIdx.x];
+    const ptrdiff_t stride = j.stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x;
+    const bool is_mip = j.is_mip, no_isp = !j.isp_split;
+    uint8_t *src = (uint8_t *)j.plane + ((ptrdiff_t)j.y * stride + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
+    uint16_t *left = arr[0] + kEdgeOrg, *top = arr[1] + kEdgeOrg, *fleft = arr[2] + kEdgeOrg, *ftop = arr[3] + kEdgeOrg;
+
+    const bool rff = is_mip ? false : ref_filter_mode(mode);
+    const bool smooth = !ref_idx && w * h > 32 && !c_idx && no_isp && rff;
+    const int ref_line = ref_idx == 3 ? -4 : -1 - ref_idx;
+    int left_size, top_size, uleft, utop, refw = 0, refh = 0, angle = 0, inv = 0;
+    if (is_mip || mode == 0)      { left_size = h + 1; top_size = w + 1; uleft = left_size + smooth; utop = top_size + smooth; }
+    else if (mode == 1)           { uleft = left_size = h; utop = top_size = w; }
+    else if (mode == 50)          { uleft = left_size = need_pdpc ? h : 1; utop = top_size = w; }
+    else if (mode == 18)          { uleft = left_size = h; utop = top_size = need_pdpc ? w : 1; }
+    else {
+        if (no_isp || c_idx) { refw = w * 2; refh = h * 2; } else { refw = j.cb_width + w; refh = j.cb_height + h; }
+        angle = intra_pred_angle(mode);
+        inv = intra_inv_angle(angle);
+        utop = top_size = refw; uleft = left_size = refh;
+    }
+    const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
+#define GETP(x, y) ld_px<BD>(src, (ptrdiff_t)(x) + stride * (ptrdiff_t)(y))
+    for (int i = tid; i < la; i += blockDim.x) left[i] = (uint16_t)GETP(ref_line, i);
+    for (int i = tid; i < ta; i += blockDim.x) top[i] = (uint16_t)GETP(i, ref_line);
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = -1; i >= ref_line; i--) {
+            if (j.cand_up_left) { left[i] = (uint16_t)GETP(ref_line, i); top[i] = (uint16_t)GETP(i, ref_line); }
+            else if (la) left[i] = top[i] = left[0];
+            else if (ta) left[i] = top[i] = top[0];
+            else left[i] = top[i] = 1 << (BD - 1);
+        }
+    }
+    __syncthreads();
+    {
+        const uint16_t tfill = top[ta - 1], lfill = left[la - 1];
+        for (int i = ta + tid; i < utop; i += blockDim.x) top[i] = tfill;
+        for (int i = la + tid; i < uleft; i += blockDim.x) left[i] = lfill;
+    }
+    __syncthreads();
+    if (rff && smooth) {                                  // ref_filter (:450)
+        const int keep_last = left_size == uleft;
+        if (tid == 0)
+            fleft[-1] = ftop[-1] = (uint16_t)((left[0] + 2 * left[-1] + top[0] + 2) >> 2);
+        for (int i = tid; i < uleft - keep_last; i += blockDim.x) fleft[i] = (uint16_t)((left[i - 1] + 2 * left[i] + left[i + 1] + 2) >> 2);
+        for (int i = tid; i < utop - keep_last; i += blockDim.x) ftop[i] = (uint16_t)((top[i - 1] + 2 * top[i] + top[i + 1] + 2) >> 2);
+        if (keep_last && tid == 0) { ftop[utop - 1] = top[utop - 1]; fleft[uleft - 1] = left[uleft - 1]; }
+        __syncthreads();
+        left = fleft; top = ftop;
+    }
+    int filter_flag = 0;
+    if (!is_mip && mode != 0 && mode != 1) {
+        if (!(rff || ref_idx || !no_isp)) {
+            const int thres[5] = { 24, 14, 2, 0, 0 };
+            const int dist = min(abs(mode - 50), abs(mode - 18));
+            filter_flag = dist > thres[max(0, ((ilog2i(w) + ilog2i(h)) >> 1) - 2)];
+        }
+        if (mode != 50 && mode != 18) {
+            if (mode >= 34) {
+                if (angle < 0) {
+                    uint16_t *p = top - (ref_idx + 1);
+                    for (int x = -h + tid; x < 0; x += blockDim.x)
+                        p[x] = left[-1 - ref_idx + min((x * inv + 256) >> 9, h)];
+                } else {
+                    const uint16_t v = top[refw - 1];
+                    for (int i = refw + tid; i <= refw + max(1, w / h) * ref_idx + 1; i += blockDim.x) top[i] = v;
+                }
+            } else {
+                if (angle < 0) {
+                    uint16_t *p = left - (ref_idx + 1);
+                    for (int x = -w + tid; x < 0; x += blockDim.x)
+                        p[x] = top[-1 - ref_idx + min((x * inv + 256) >> 9, w)];
+                } else {
+                    const uint16_t v = left[refh - 1];
+                    for (int i = refh + tid; i <= refh + max(1, h / w) * ref_idx + 1; i += blockDim.x) left[i] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    LRef T{ top }, L{ left };
+    if (is_mip)          pred_mip<BD>(src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch);
+    else if (mode == 0)  pred_planar<BD>(src, stride, T, L, w, h);
+    else if (mode == 1)  pred_dc<BD>(src, stride, T, L, w, h, scratch);
+    else if (mode == 50) pred_vh<BD>(src, stride, T, w, h, true);
+    else if (mode == 18) pred_vh<BD>(src, stride, L, w, h, false);
+    else                 pred_angular<BD>(src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc);
+
+    if (need_pdpc && !is_mip && (mode == 0 || mode == 1 || mode == 50 || mode == 18)) {      // :654-682
+        __syncthreads();
+        const int scale = (ilog2i(w) + ilog2i(h) - 2) >> 2;
+        for (int i = tid; i < w * h; i += blockDim.x) {
+            const int y = i / w, x = i - y * w;
+            const int val = GETP(x, y);
+            int l, t, wl, wt;
+            if (mode == 0 || mode == 1) {
+                l = left[y]; t = top[x];
+                wl = 32 >> min((x << 1) >> scale, 31);
+                wt = 32 >> min((y << 1) >> scale, 31);
+            } else {
+                l = left[y] - left[-1] + val; t = top[x] - top[-1] + val;
+                wl = mode == 50 ? 32 >> min((x << 1) >> scale, 31) : 0;
+                wt = mode == 18 ? 32 >> min((y << 1) >> scale, 31) : 0;
+            }
+            st_px<BD>(src, x + stride * y, clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
+        }
+    }
+#undef GETP
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+static void check_intra_dims(int w, int h)
+{
+    if (w <= 0 || h <= 0 || w > 128 || h > 128 || (w & (w - 1)) || (h & (h - 1))) {
+        fprintf(stderr, "vvc_mi355: intra block %dx%d outside the slot's domain (powers of two <= 128)\n", w, h);
+        abort();
+    }
+}
+
+// [lo, hi] index range of the main reference that pred_angular reads
+static void angular_main_range(int n_along, int n_across, int c_idx, int mode, int ref_idx, int filter_flag, int *lo, int *hi)
+{
+    const int angle = intra_pred_angle(mode);
+    *lo = 1 << 30; *hi = -(1 << 30);
+    for (int across = 0; across < n_across; across++) {
+        const int pos = (1 + ref_idx + across) * angle;
+        const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
+        int a, b;
+        if (!fact && (c_idx || !filter_flag)) { a = b = 1; }
+        else if (!c_idx) { a = 0; b = 3; }
+        else { a = 1; b = 2; }
+        const int base = -(1 + ref_idx) + idx;
+        if (base + a < *lo) *lo = base + a;
+        if (base + n_along - 1 + b > *hi) *hi = base + n_along - 1 + b;
+    }
+}
+
+static void slot_leaf(int bd, int kind, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+                      int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc, int mip_mode, int mip_transposed)
+{
+    check_intra_dims(w, h);
+    const int px = bd > 8 ? 2 : 1;
+    int t_lo = 0, t_hi = -1, l_lo = 0, l_hi = -1;       // inclusive sample ranges read from top / left
+    switch (kind) {
+    case 0: t_hi = w; l_hi = h; break;
+    case 1: if (w >= h) t_hi = w - 1; if (w <= h) l_hi = h - 1; break;
+    case 2: t_hi = w - 1; break;
+    case 3: l_hi = h - 1; break;
+    case 6: t_hi = w - 1; l_hi = h - 1; break;
+    default: {
+        const bool vertical = kind == 4;
+        int lo, hi;
+        angular_main_range(vertical ? w : h, vertical ? h : w, c_idx, mode, ref_idx, filter_flag, &lo, &hi);
+        if (vertical) { t_lo = lo; t_hi = hi; } else { l_lo = lo; l_hi = hi; }
+        if (need_pdpc) {
+            const int inv = intra_inv_angle(intra_pred_angle(mode)), nscale = intra_nscale(w, h, mode);
+            int slo = 1 << 30, shi = -(1 << 30);
+            const int n_side = vertical ? h : w, n_pd = vertical ? (w < (3 << nscale) ? w : (3 << nscale)) : (h < (3 << nscale) ? h : (3 << nscale));
+            for (int k = 0; k < n_pd; k++) {
+                const int o = (256 + (k + 1) * inv) >> 9;
+                if (o < slo) slo = o;
+                if (o + n_side - 1 > shi) shi = o + n_side - 1;
+            }
+            if (n_pd > 0) { if (vertical) { l_lo = slo; l_hi = shi; } else { t_lo = slo; t_hi = shi; } }
+        }
+    } }
+    SlotCall call;
+    LeafArgs a = {};
+    const int w_store = (kind == 1 || kind == 3) ? (w + 3) & ~3 : w;
+    const Staged d = call.rect(src, stride * px, 0, w_store * px, 0, h, false, true);
+    a.src = d.dev; a.stride = (int)(d.pitch / px);
+    if (t_hi >= t_lo) a.top = (const uint8_t *)call.linear(top + (ptrdiff_t)t_lo * px, (size_t)(t_hi - t_lo + 1) * px, true, false) - (ptrdiff_t)t_lo * px;
+    if (l_hi >= l_lo) a.left = (const uint8_t *)call.linear(left + (ptrdiff_t)l_lo * px, (size_t)(l_hi - l_lo + 1) * px, true, false) - (ptrdiff_t)l_lo * px;
+    a.w = w; a.h = h; a.kind = kind; a.c_idx = c_idx; a.mode = mode; a.ref_idx = ref_idx; a.filter_flag = filter_flag;
+    a.need_pdpc = need_pdpc; a.mip_mode = mip_mode; a.mip_transposed = mip_transposed;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((intra_leaf_kernel<BD>), dim3(1), dim3(256), 0, call.stream(), a));
+    HIP_CHECK(hipGetLastError());
+}
+
+} // namespace vvc355
+
+using namespace vvc355;
+
+extern "C" {
+
+void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs)
+{
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((intra_pred_kernel<BD>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_pred_planar(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride)
+{
+    slot_leaf(bd, 0, src, top, left, w, h, stride, 0, 0, 0, 0, 0, 0, 0);
+}
+void vvc355_pred_dc(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride)
+{
+    slot_leaf(bd, 1, src, top, left, w, h, stride, 0, 0, 0, 0, 0, 0, 0);
+}
+void vvc355_pred_v(int bd, uint8_t *src, const uint8_t *top, int w, int h, ptrdiff_t stride)
+{
+    slot_leaf(bd, 2, src, top, nullptr, w, h, stride, 0, 0, 0, 0, 0, 0, 0);
+}
+void vvc355_pred_h(int bd, uint8_t *src, const uint8_t *left, int w, int h, ptrdiff_t stride)
+{
+    slot_leaf(bd, 3, src, nullptr, left, w, h, stride, 0, 0, 0, 0, 0, 0, 0);
+}
+void vvc355_pred_angular_v(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+                           int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
+{
+    slot_leaf(bd, 4, src, top, left, w, h, stride, c_idx, mode, ref_idx, filter_flag, need_pdpc, 0, 0);
+}
+void vvc355_pred_angular_h(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+                           int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
+{
+    slot_leaf(bd, 5, src, top, left, w, h, stride, c_idx, mode, ref_idx, filter_flag, need_pdpc, 0, 0);
+}
+void vvc355_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+                     int mode_id, int is_transpose)
+{
+    slot_leaf(bd, 6, src, top, left, w, h, stride, 0, 0, 0, 0, 0, mode_id, is_transpose);
+}
+
+// intra_pred with the context flattened; job->plane is a HOST address here, the touched window is staged
+void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
+{
+    check_intra_dims(job->w, job->h);
+    const int px = bd > 8 ? 2 : 1;
+    // window of the plane the slot can touch: 4 reference lines up/left, up to cb + block (ISP) or 2x block samples down/right
+    const int reach_x = job->w + (job->isp_split && !job->c_idx ? (job->cb_width > job->w ? job->cb_width : job->w) : job->w) + 4;
+    const int reach_y = job->h + (job->isp_split && !job->c_idx ? (job->cb_height > job->h ? job->cb_height : job->h) : job->h) + 4;
+    const int x0 = job->x - 4 > 0 ? job->x - 4 : 0, y0 = job->y - 4 > 0 ? job->y - 4 : 0;
+    const int x1 = job->x + reach_x < job->plane_w ? job->x + reach_x : job->plane_w;
+    const int y1 = job->y + reach_y < job->plane_h ? job->y + reach_y : job->plane_h;
+    SlotCall call;
+    uint8_t *org = (uint8_t *)(uintptr_t)job->plane + (ptrdiff_t)y0 * job->stride + (ptrdiff_t)x0 * px;
+    const Staged s = call.rect(org, job->stride, 0, (ptrdiff_t)(x1 - x0) * px, 0, y1 - y0, true, true);
+    vvc355_intra_job dj = *job;
+    dj.plane = (uint64_t)(s.dev - (ptrdiff_t)y0 * s.pitch - (ptrdiff_t)x0 * px);
+    dj.stride = (int32_t)s.pitch;
+    vvc355_intra_pred_batch(call.stream(), bd, call.upload(&dj, 1), 1);
+}
+
+} // extern "C"

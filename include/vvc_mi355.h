@@ -257,6 +257,48 @@ void vvc355_add_residual_joint(int bd, uint8_t *dst, const int *res, int width, 
 void vvc355_pred_residual_joint(int *buf, int width, int height, int c_sign, int shift);
 void vvc355_transform_bdpcm(int *coeffs, int width, int height, int vertical, int log2_transform_range);
 
+/* ------------------------------------------------------------------ intra prediction (intra.hip) */
+
+/*
+ * VVCIntraDSPContext.intra_pred (vvcdsp.h:100, vvc_intra_template.c:595) with everything it reads through
+ * VVCLocalContext flattened (SURVEY 8b "fat slots"):
+ *   mode        = intra mode AFTER ff_vvc_wide_angle_mode_mapping (vvc_intra.c:693), -14..80
+ *   left_avail  = ff_vvc_get_left_available(lc, x, y, <unbounded>, c_idx)   (vvc_intra.c:622)
+ *   top_avail   = ff_vvc_get_top_available (lc, x, y, <unbounded>, c_idx)   (vvc_intra.c:591)
+ *   cand_up_left= lc->na.cand_up_left; isp_split = cu->isp_split_type != ISP_NO_SPLIT; cb_* = cu->cb_width/height
+ *   is_mip / mip_mode / mip_transposed = fc->tab.imf / imm / imtf at the block (and mip_chroma_direct_flag for chroma)
+ * plane = address of sample (0,0) of the component plane; x, y, w, h in component samples.
+ */
+typedef struct vvc355_intra_job {
+    uint64_t plane;
+    int32_t  stride;              /* bytes */
+    int16_t  x, y, w, h;
+    int16_t  mode;
+    int16_t  cb_width, cb_height;
+    int16_t  left_avail, top_avail;
+    int16_t  plane_w, plane_h;    /* component picture size (bounds what the synchronous entry stages) */
+    uint8_t  c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag, cand_up_left;
+    uint8_t  pad_[6];
+} vvc355_intra_job;
+
+/* jobs of one launch must not depend on each other's output (e.g. one anti-diagonal of the RECON wavefront) */
+void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs);
+/* synchronous form: job->plane is a HOST address */
+void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job);
+
+/* Leaf predictors — vvcdsp.h:101-110.  As in the reference (POS(), vvc_intra_template.c:27) `stride` counts PIXELS.
+ * top/left are the prepared reference arrays (negative indices are read by the angular modes). */
+void vvc355_pred_planar(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);   /* :686 */
+void vvc355_pred_dc(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);       /* :847 */
+void vvc355_pred_v(int bd, uint8_t *src, const uint8_t *top, int w, int h, ptrdiff_t stride);                             /* :866 */
+void vvc355_pred_h(int bd, uint8_t *src, const uint8_t *left, int w, int h, ptrdiff_t stride);                            /* :877 */
+void vvc355_pred_angular_v(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc);                                                    /* :894 */
+void vvc355_pred_angular_h(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc);                                                    /* :950 */
+void vvc355_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
+    int mode_id, int is_transpose);                                                                                       /* :773 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,7 +94,24 @@ void orc_add_residual_joint(int bd, uint8_t *dst, const int *res, int width, int
 void orc_pred_residual_joint(int *buf, int width, int height, int c_sign, int shift);
 void orc_transform_bdpcm(int *coeffs, int width, int height, int vertical, int log2_transform_range);
 
-/* ---- intra leaf predictors (orc_intra.c) ---- */
+/* ---- intra (orc_intra.c).  Leaf predictors: `stride` counts PIXELS, like the reference's POS() macro. ---- */
+/* intra_pred with VVCLocalContext flattened; same layout as vvc355_intra_job (include/vvc_mi355.h), plane = HOST address */
+typedef struct orc_intra_job {
+    uint64_t plane;
+    int32_t  stride;
+    int16_t  x, y, w, h;
+    int16_t  mode;
+    int16_t  cb_width, cb_height;
+    int16_t  left_avail, top_avail;
+    int16_t  plane_w, plane_h;
+    uint8_t  c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag, cand_up_left;
+    uint8_t  pad_[6];
+} orc_intra_job;
+void orc_intra_pred_flat(int bd, const orc_intra_job *job);
+int  orc_intra_pred_angle(int mode);
+int  orc_intra_inv_angle(int angle);
+int  orc_intra_nscale(int w, int h, int mode);
+int  orc_intra_need_pdpc(int w, int h, int bdpcm_flag, int mode, int ref_idx);
 void orc_pred_planar(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);
 void orc_pred_dc(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride);
 void orc_pred_v(int bd, uint8_t *src, const uint8_t *top, int w, int h, ptrdiff_t stride);
