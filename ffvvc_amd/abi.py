@@ -72,6 +72,12 @@ SLOT_SIGNATURES = {
     "intra_pred_flat":    ("v", "ip"),
 }
 
+# flattened "fat" slots whose signatures differ between the product (needs staging bounds) and the oracle
+FLAT_SIGNATURES = {
+    "intra_cclm_pred_flat":    ("v", "ipii"),
+    "lmcs_scale_chroma_flat":  ("v", "ipppii"),
+}
+
 RUNTIME_SIGNATURES = {
     "device_count":   ("i", ""),
     "set_device":     ("v", "i"),
@@ -97,6 +103,7 @@ BATCH_SIGNATURES = {
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipi"),
     "intra_pred_batch": ("v", "pipi"),
+    "cclm_batch":       ("v", "pipi"),
 }
 
 
@@ -123,6 +130,7 @@ def load() -> ctypes.CDLL:
         bind(lib, "vvc355_", SLOT_SIGNATURES)
         bind(lib, "vvc355_", RUNTIME_SIGNATURES)
         bind(lib, "vvc355_", BATCH_SIGNATURES)
+        bind(lib, "vvc355_", FLAT_SIGNATURES)
         _lib = lib
     return _lib
 
@@ -207,4 +215,27 @@ class IntraJob(ctypes.Structure):
         ("c_idx", ctypes.c_uint8), ("ref_idx", ctypes.c_uint8), ("is_mip", ctypes.c_uint8), ("mip_mode", ctypes.c_uint8),
         ("mip_transposed", ctypes.c_uint8), ("isp_split", ctypes.c_uint8), ("bdpcm_flag", ctypes.c_uint8),
         ("cand_up_left", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6),
+    ]
+
+
+class CclmJob(ctypes.Structure):
+    """Mirror of vvc355_cclm_job / orc_cclm_job."""
+    _fields_ = [
+        ("luma", ctypes.c_uint64), ("cb", ctypes.c_uint64), ("cr", ctypes.c_uint64),
+        ("luma_stride", ctypes.c_int32), ("cb_stride", ctypes.c_int32), ("cr_stride", ctypes.c_int32),
+        ("x0", ctypes.c_int16), ("y0", ctypes.c_int16), ("width", ctypes.c_int16), ("height", ctypes.c_int16),
+        ("top_avail_c", ctypes.c_int16), ("left_avail_c", ctypes.c_int16),
+        ("mode", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("avail_t", ctypes.c_uint8),
+        ("avail_l", ctypes.c_uint8), ("collocated", ctypes.c_uint8), ("ctu_boundary", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
+    ]
+
+
+class LmcsScaleJob(ctypes.Structure):
+    """Mirror of vvc355_lmcs_scale_job / orc_lmcs_scale_job."""
+    _fields_ = [
+        ("luma", ctypes.c_uint64), ("luma_stride", ctypes.c_int32),
+        ("x_vpdu", ctypes.c_int16), ("y_vpdu", ctypes.c_int16), ("pic_w", ctypes.c_int16), ("pic_h", ctypes.c_int16),
+        ("size_y", ctypes.c_int16),
+        ("avail_t", ctypes.c_uint8), ("avail_l", ctypes.c_uint8), ("min_bin_idx", ctypes.c_uint8), ("max_bin_idx", ctypes.c_uint8),
+        ("pivot", ctypes.c_uint16 * 17), ("chroma_scale_coeff", ctypes.c_uint16 * 16), ("pad_", ctypes.c_uint16 * 6),
     ]

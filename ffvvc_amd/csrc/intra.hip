@@ -506,3 +506,265 @@ void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
 }
 
 } // extern "C"
+
+// ================================================================================================ CCLM + LMCS chroma scaling
+// intra_cclm_pred (vvc_intra_template.c:352, helpers :29-349) and lmcs_scale_chroma (:431, :390) with the decoder
+// context flattened into job descriptors.
+
+namespace vvc355 {
+
+template <int BD>
+__device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, int cx, int cy)
+{
+    const uint8_t *luma = (const uint8_t *)j.luma;
+    const ptrdiff_t s = j.luma_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int hs = j.hs, vs = j.vs;
+    const ptrdiff_t o = (ptrdiff_t)(j.y0 + (cy << vs)) * s + j.x0 + (cx << hs);
+#define L(dx, dy) ld_px<BD>(luma, o + (dx) + (dy) * s)
+    if (!hs && !vs)
+        return L(0, 0);
+    const int lx = (cx || j.avail_l) ? -1 : 0;
+    if (!vs)
+        return (L(lx, 0) + 2 * L(0, 0) + L(1, 0) + 2) >> 2;
+    if (j.collocated) {
+        const int ty = (cy || j.avail_t) ? -1 : 0;
+        return (L(lx, 0) + L(0, ty) + 4 * L(0, 0) + L(1, 0) + L(0, 1) + 4) >> 3;
+    }
+    return (L(lx, 0) + L(lx, 1) + 2 * L(0, 0) + 2 * L(0, 1) + L(1, 0) + L(1, 1) + 4) >> 3;
+#undef L
+}
+
+template <int BD>
+__global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__restrict__ jobs)
+{
+    __shared__ int prm[6];        // a[2], b[2], k[2]
+    const vvc355_cclm_job j = jobs[blockIdx.x];
+    using px_t = typename Px<BD>::type;
+    const int hs = j.hs, vs = j.vs;
+    const int x = j.x0 >> hs, y = j.y0 >> vs, w = j.width >> hs, h = j.height >> vs;
+    const int avail_t = j.avail_t, avail_l = j.avail_l;
+    uint8_t *cpl[2] = { (uint8_t *)j.cb, (uint8_t *)j.cr };
+    const ptrdiff_t cs[2] = { j.cb_stride / (ptrdiff_t)sizeof(px_t), j.cr_stride / (ptrdiff_t)sizeof(px_t) };
+
+    if (!avail_t && !avail_l) {
+        for (int i = threadIdx.x; i < 2 * w * h; i += blockDim.x) {
+            const int c = i / (w * h), r = i - c * w * h, yy = r / w, xx = r - yy * w;
+            st_px<BD>(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, 1 << (BD - 1));
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const uint8_t *luma = (const uint8_t *)j.luma;
+        const ptrdiff_t ls = j.luma_stride / (ptrdiff_t)sizeof(px_t);
+        int a[2] = { 0, 0 }, b[2] = { 1 << (BD - 1), 1 << (BD - 1) }, k[2] = { 0, 0 };
+        int cnt[2] = { 0, 0 }, pos[2][4], have = 0;
+        const int lt = j.mode == 81;
+        const int is4 = !avail_t || !avail_l || !lt;
+        int num[2];
+        if (lt) { num[0] = avail_t ? w : 0; num[1] = avail_l ? h : 0; }
+        else {
+            num[0] = (avail_t && j.mode == 83) ? min(w + min(w, h), (int)j.top_avail_c) : 0;
+            num[1] = (avail_l && j.mode == 82) ? min(h + min(w, h), (int)j.left_avail_c) : 0;
+        }
+        if (num[0] || num[1]) {
+            have = 1;
+            for (int i = 0; i < 2; i++) {
+                const int start = num[i] >> (2 + is4), step = max(1, num[i] >> (1 + is4));
+                cnt[i] = min(num[i], (1 + is4) << 1);
+                for (int c = 0; c < 4; c++)
+                    pos[i][c] = start + c * step;
+            }
+        }
+        if (have) {
+            int sel[3][8];
+            for (int c = 0; c < 3; c++) for (int i = 0; i < 8; i++) sel[c][i] = 0;
+            const ptrdiff_t lo = (ptrdiff_t)j.y0 * ls + j.x0;
+#define LP(off) ld_px<BD>(luma, (off))
+            for (int i = 0; i < cnt[0]; i++) {
+                if (!hs && !vs) { sel[0][i] = LP(lo - avail_t * ls + pos[0][i]); continue; }
+                const int xx = pos[0][i] << hs;
+                const int has_left = xx || avail_l;
+                if (vs && !j.ctu_boundary) {
+                    const ptrdiff_t o = lo - 2 * ls + xx;
+                    const int l = has_left ? LP(o - 1) : LP(o);
+                    if (j.collocated)
+                        sel[0][i] = (LP(o - ls) + l + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+                    else {
+                        const int l1 = has_left ? LP(o - 1 + ls) : LP(o + ls);
+                        sel[0][i] = (l + l1 + 2 * (LP(o) + LP(o + ls)) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+                    }
+                } else {
+                    const ptrdiff_t o = lo - ls + xx;
+                    const int l = has_left ? LP(o - 1) : LP(o);
+                    sel[0][i] = (l + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+                }
+            }
+            for (int i = 0; i < cnt[1]; i++) {
+                if (!hs && !vs) { sel[0][cnt[0] + i] = LP(lo - avail_l + (ptrdiff_t)pos[1][i] * ls); continue; }
+                const int yy = pos[1][i] << vs;
+                const ptrdiff_t o = lo - (1 + hs) * avail_l + (ptrdiff_t)yy * ls, l = o - avail_l;
+                int p;
+                if (!vs)
+                    p = (LP(l) + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+                else if (j.collocated) {
+                    const int t = (yy || avail_t) ? LP(o - ls) : LP(o);
+                    p = (LP(l) + t + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+                } else
+                    p = (LP(l) + LP(l + ls) + 2 * LP(o) + 2 * LP(o + ls) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+                sel[0][cnt[0] + i] = p;
+            }
+#undef LP
+            for (int c = 0; c < 2; c++) {
+                for (int i = 0; i < cnt[0]; i++)
+                    sel[c + 1][i] = ld_px<BD>(cpl[c], (ptrdiff_t)(y - 1) * cs[c] + x + pos[0][i]);
+                for (int i = 0; i < cnt[1]; i++)
+                    sel[c + 1][cnt[0] + i] = ld_px<BD>(cpl[c], (ptrdiff_t)(y + pos[1][i]) * cs[c] + x - 1);
+            }
+            if (cnt[0] + cnt[1] == 2)
+                for (int c = 0; c < 3; c++) {
+                    sel[c][3] = sel[c][0]; sel[c][2] = sel[c][1]; sel[c][0] = sel[c][1]; sel[c][1] = sel[c][3];
+                }
+            int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3, t;
+#define SWAP(p, q) do { t = p; p = q; q = t; } while (0)
+            if (sel[0][mn0] > sel[0][mn1]) SWAP(mn0, mn1);
+            if (sel[0][mx0] > sel[0][mx1]) SWAP(mx0, mx1);
+            if (sel[0][mn0] > sel[0][mx1]) { SWAP(mn0, mx0); SWAP(mn1, mx1); }
+            if (sel[0][mn1] > sel[0][mx0]) SWAP(mn1, mx0);
+#undef SWAP
+            int vmax[3], vmin[3];
+            for (int c = 0; c < 3; c++) {
+                vmax[c] = (sel[c][mx0] + sel[c][mx1] + 1) >> 1;
+                vmin[c] = (sel[c][mn0] + sel[c][mn1] + 1) >> 1;
+            }
+            const int diff = vmax[0] - vmin[0];
+            for (int i = 0; i < 2; i++) {
+                if (!diff) { a[i] = k[i] = 0; b[i] = vmin[i + 1]; continue; }
+                const int div_sig[16] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 };
+                const int diffc = vmax[i + 1] - vmin[i + 1];
+                int xl = ilog2(diff);
+                const int norm = ((diff << 4) >> xl) & 15;
+                xl += norm ? 1 : 0;
+                const int yl = abs(diffc) > 0 ? ilog2(abs(diffc)) + 1 : 0;
+                const int v = div_sig[norm] | 8;
+                a[i] = (diffc * v + ((1 << yl) >> 1)) >> yl;
+                k[i] = max(1, 3 + xl - yl);
+                if (3 + xl - yl < 1)
+                    a[i] = sign_of(a[i]) * 15;
+                b[i] = vmin[i + 1] - ((a[i] * vmin[0]) >> k[i]);
+            }
+        }
+        prm[0] = a[0]; prm[1] = a[1]; prm[2] = b[0]; prm[3] = b[1]; prm[4] = k[0]; prm[5] = k[1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        const int dsy = cclm_ds_luma<BD>(j, xx, yy);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            st_px<BD>(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, clip_px<BD>(((dsy * prm[c]) >> prm[4 + c]) + prm[2 + c]));
+    }
+}
+
+template <int BD>
+__device__ int lmcs_chroma_scale(const vvc355_lmcs_scale_job &j)
+{
+    const uint8_t *luma = (const uint8_t *)j.luma;
+    const ptrdiff_t s = j.luma_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int size = j.size_y, x = j.x_vpdu, y = j.y_vpdu;
+    int cnt = 0, sum = 0;
+    if (j.avail_l) {
+        const int n = min(j.pic_h - y, size);
+        for (int i = 0; i < n; i++) sum += ld_px<BD>(luma, (ptrdiff_t)(y + i) * s + x - 1);
+        sum += ld_px<BD>(luma, (ptrdiff_t)(y + n - 1) * s + x - 1) * (size - n);
+        cnt = size;
+    }
+    if (j.avail_t) {
+        const int n = min(j.pic_w - x, size);
+        for (int i = 0; i < n; i++) sum += ld_px<BD>(luma, (ptrdiff_t)(y - 1) * s + x + i);
+        sum += ld_px<BD>(luma, (ptrdiff_t)(y - 1) * s + x + n - 1) * (size - n);
+        cnt += size;
+    }
+    const int avg = cnt ? (sum + (cnt >> 1)) >> ilog2(cnt) : 1 << (BD - 1);
+    int i;
+    for (i = j.min_bin_idx; i <= j.max_bin_idx; i++)
+        if (avg < j.pivot[i + 1])
+            break;
+    return j.chroma_scale_coeff[min(i, 15)];
+}
+
+// one workgroup: lane 0 derives the scale, then all lanes scale the residual block
+template <int BD>
+__global__ __launch_bounds__(256) void lmcs_scale_kernel(const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int n)
+{
+    __shared__ int scale;
+    if (threadIdx.x == 0)
+        scale = lmcs_chroma_scale<BD>(*job);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = clip_intp2(coeff[i], BD);
+        dst[i] = c > 0 ? (c * scale + (1 << 10)) >> 11 : -((-c * scale + (1 << 10)) >> 11);
+    }
+}
+
+} // namespace vvc355
+
+extern "C" {
+
+void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, int n_jobs)
+{
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((vvc355::cclm_kernel<BD>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    HIP_CHECK(hipGetLastError());
+}
+
+// job->luma/cb/cr are HOST addresses of sample (0,0) of each plane; pic_* bound what is staged
+void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h)
+{
+    using namespace vvc355;
+    const int px = bd > 8 ? 2 : 1;
+    const int hs = job->hs, vs = job->vs;
+    // luma window: block + 2 rows above, 3 columns left, 1 extra row/column, and the T/L extension (2x the block)
+    const int lx0 = job->x0 - 4 > 0 ? job->x0 - 4 : 0, ly0 = job->y0 - 4 > 0 ? job->y0 - 4 : 0;
+    const int lx1 = job->x0 + 2 * job->width + 4 < pic_w ? job->x0 + 2 * job->width + 4 : pic_w;
+    const int ly1 = job->y0 + 2 * job->height + 4 < pic_h ? job->y0 + 2 * job->height + 4 : pic_h;
+    const int cw = pic_w >> hs, ch = pic_h >> vs;
+    const int cx0 = lx0 >> hs, cy0 = ly0 >> vs;
+    const int cx1 = ((lx1 + (1 << hs) - 1) >> hs) < cw ? ((lx1 + (1 << hs) - 1) >> hs) : cw;
+    const int cy1 = ((ly1 + (1 << vs) - 1) >> vs) < ch ? ((ly1 + (1 << vs) - 1) >> vs) : ch;
+    SlotCall call;
+    vvc355_cclm_job dj = *job;
+    const Staged l = call.rect((uint8_t *)(uintptr_t)job->luma + (ptrdiff_t)ly0 * job->luma_stride + (ptrdiff_t)lx0 * px,
+                               job->luma_stride, 0, (ptrdiff_t)(lx1 - lx0) * px, 0, ly1 - ly0, true, false);
+    dj.luma = (uint64_t)(l.dev - (ptrdiff_t)ly0 * l.pitch - (ptrdiff_t)lx0 * px); dj.luma_stride = (int32_t)l.pitch;
+    const Staged b = call.rect((uint8_t *)(uintptr_t)job->cb + (ptrdiff_t)cy0 * job->cb_stride + (ptrdiff_t)cx0 * px,
+                               job->cb_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, true);
+    dj.cb = (uint64_t)(b.dev - (ptrdiff_t)cy0 * b.pitch - (ptrdiff_t)cx0 * px); dj.cb_stride = (int32_t)b.pitch;
+    const Staged r = call.rect((uint8_t *)(uintptr_t)job->cr + (ptrdiff_t)cy0 * job->cr_stride + (ptrdiff_t)cx0 * px,
+                               job->cr_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, true);
+    dj.cr = (uint64_t)(r.dev - (ptrdiff_t)cy0 * r.pitch - (ptrdiff_t)cx0 * px); dj.cr_stride = (int32_t)r.pitch;
+    vvc355_cclm_batch(call.stream(), bd, call.upload(&dj, 1), 1);
+}
+
+// job->luma is a HOST address; dst/coeff are host int arrays of width*height
+void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height)
+{
+    using namespace vvc355;
+    if (width <= 0 || height <= 0) return;
+    const int px = bd > 8 ? 2 : 1, n = width * height;
+    const int x = job->x_vpdu, y = job->y_vpdu;
+    const int x0 = x > 0 ? x - 1 : 0, y0 = y > 0 ? y - 1 : 0;
+    const int x1 = x + job->size_y < job->pic_w ? x + job->size_y : job->pic_w;
+    const int y1 = y + job->size_y < job->pic_h ? y + job->size_y : job->pic_h;
+    SlotCall call;
+    vvc355_lmcs_scale_job dj = *job;
+    const Staged l = call.rect((uint8_t *)(uintptr_t)job->luma + (ptrdiff_t)y0 * job->luma_stride + (ptrdiff_t)x0 * px,
+                               job->luma_stride, 0, (ptrdiff_t)(x1 - x0) * px, 0, y1 - y0, true, false);
+    dj.luma = (uint64_t)(l.dev - (ptrdiff_t)y0 * l.pitch - (ptrdiff_t)x0 * px); dj.luma_stride = (int32_t)l.pitch;
+    int *d_dst = (int *)call.linear(dst, (size_t)n * sizeof(int), false, true);
+    const int *d_coeff = (const int *)call.linear(coeff, (size_t)n * sizeof(int), true, false);
+    const vvc355_lmcs_scale_job *jd = call.upload(&dj, 1);
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((lmcs_scale_kernel<BD>), dim3(1), dim3(256), 0, call.stream(), jd, d_dst, d_coeff, n));
+    HIP_CHECK(hipGetLastError());
+}
+
+} // extern "C"

@@ -299,6 +299,39 @@ void vvc355_pred_angular_h(int bd, uint8_t *src, const uint8_t *top, const uint8
 void vvc355_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
     int mode_id, int is_transpose);                                                                                       /* :773 */
 
+/*
+ * VVCIntraDSPContext.intra_cclm_pred (vvcdsp.h:98, vvc_intra_template.c:352) flattened.  x0,y0,width,height in LUMA
+ * samples like the slot; mode = cu->intra_pred_mode_c (81 LT_CCLM, 82 L_CCLM, 83 T_CCLM); avail_t/avail_l =
+ * ff_vvc_get_{top,left}_available(lc, x0, y0, 1, 0) != 0; top_avail_c/left_avail_c = the same functions on the chroma
+ * block for an unbounded request (c_idx 1); collocated = sps_chroma_vertical_collocated_flag;
+ * ctu_boundary = (y0 % ctb_size == 0).  luma/cb/cr = address of sample (0,0) of each plane.
+ */
+typedef struct vvc355_cclm_job {
+    uint64_t luma, cb, cr;
+    int32_t  luma_stride, cb_stride, cr_stride;     /* bytes */
+    int16_t  x0, y0, width, height;
+    int16_t  top_avail_c, left_avail_c;
+    uint8_t  mode, hs, vs, avail_t, avail_l, collocated, ctu_boundary, pad_;
+} vvc355_cclm_job;
+
+/* VVCIntraDSPContext.lmcs_scale_chroma (vvcdsp.h:99, vvc_intra_template.c:431 + :390) flattened: the 64x64 VPDU origin
+ * (x_vpdu, y_vpdu) of the CU, neighbour availability there, picture size, min(ctb_size, 64) and the LMCS model
+ * (fc->ps.lmcs.{min_bin_idx,max_bin_idx,pivot[17],chroma_scale_coeff[16]}, vvc_ps.h:193-202). */
+typedef struct vvc355_lmcs_scale_job {
+    uint64_t luma;
+    int32_t  luma_stride;
+    int16_t  x_vpdu, y_vpdu, pic_w, pic_h, size_y;
+    uint8_t  avail_t, avail_l, min_bin_idx, max_bin_idx;
+    uint16_t pivot[17];
+    uint16_t chroma_scale_coeff[16];
+    uint16_t pad_[6];
+} vvc355_lmcs_scale_job;
+
+void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, int n_jobs);
+/* synchronous forms: plane addresses are HOST addresses; pic_w/pic_h (luma samples) bound what is staged */
+void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h);
+void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -394,3 +394,195 @@ ORC_API void orc_intra_pred_flat(int bd, const orc_intra_job *j)
             }
     }
 }
+
+/* ------------------------------------------------------------------ CCLM with the decoder context flattened */
+
+/* down-sampled luma sample co-located with chroma (cx, cy) of the block (vvc_intra_template.c:278-334) */
+static int cclm_ds_luma(const orc_cclm_job *j, int wide, int cx, int cy)
+{
+    const uint8_t *luma = (const uint8_t *)(uintptr_t)j->luma;
+    const ptrdiff_t s = j->luma_stride >> wide;
+    const int hs = j->hs, vs = j->vs;
+    const ptrdiff_t o = (ptrdiff_t)(j->y0 + (cy << vs)) * s + j->x0 + (cx << hs);
+#define L(dx, dy) orc_ld(luma, o + (dx) + (dy) * s, wide)
+    if (!hs && !vs)
+        return L(0, 0);
+    /* left neighbour: one luma sample to the left, except in column 0 without a left neighbour (:286,:300,:308,:319) */
+    const int lx = (cx || j->avail_l) ? -1 : 0;
+    if (!vs)
+        return (L(lx, 0) + 2 * L(0, 0) + L(1, 0) + 2) >> 2;
+    if (j->collocated) {
+        /* sample above: the row above, except in row 0 without a top neighbour (:287,:333) */
+        const int ty = (cy || j->avail_t) ? -1 : 0;
+        return (L(lx, 0) + L(0, ty) + 4 * L(0, 0) + L(1, 0) + L(0, 1) + 4) >> 3;
+    }
+    return (L(lx, 0) + L(lx, 1) + 2 * L(0, 0) + 2 * L(0, 1) + L(1, 0) + L(1, 1) + 4) >> 3;
+#undef L
+}
+
+/* vvc_intra_template.c:352 (+ :29-277).  Returns nothing; writes the Cb and Cr predictions of the block. */
+ORC_API void orc_intra_cclm_pred_flat(int bd, const orc_cclm_job *j)
+{
+    const int wide = bd > 8;
+    const int hs = j->hs, vs = j->vs;
+    const int x = j->x0 >> hs, y = j->y0 >> vs, w = j->width >> hs, h = j->height >> vs;
+    const int avail_t = j->avail_t, avail_l = j->avail_l;
+    uint8_t *cpl[2] = { (uint8_t *)(uintptr_t)j->cb, (uint8_t *)(uintptr_t)j->cr };
+    const ptrdiff_t cs[2] = { j->cb_stride >> wide, j->cr_stride >> wide };
+    const uint8_t *luma = (const uint8_t *)(uintptr_t)j->luma;
+    const ptrdiff_t ls = j->luma_stride >> wide;
+    int a[2] = { 0, 0 }, b[2], k[2] = { 0, 0 };
+    b[0] = b[1] = 1 << (bd - 1);
+
+    if (!avail_t && !avail_l) {                                   /* cclm_pred_default :335 */
+        for (int c = 0; c < 2; c++)
+            for (int yy = 0; yy < h; yy++)
+                for (int xx = 0; xx < w; xx++)
+                    orc_st(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, 1 << (bd - 1), wide);
+        return;
+    }
+
+    /* --- parameter derivation: cclm_get_select_pos :58, cclm_select_* :86-211, min/max :213, a/b/k :238 */
+    int cnt[2] = { 0, 0 }, pos[2][4], have = 0;
+    {
+        const int lt = j->mode == 81;
+        const int is4 = !avail_t || !avail_l || !lt;
+        int num[2];
+        if (lt) { num[0] = avail_t ? w : 0; num[1] = avail_l ? h : 0; }
+        else {
+            num[0] = (avail_t && j->mode == 83) ? orc_min(w + orc_min(w, h), j->top_avail_c) : 0;
+            num[1] = (avail_l && j->mode == 82) ? orc_min(h + orc_min(w, h), j->left_avail_c) : 0;
+        }
+        if (num[0] || num[1]) {
+            have = 1;
+            for (int i = 0; i < 2; i++) {
+                const int start = num[i] >> (2 + is4), step = orc_max(1, num[i] >> (1 + is4));
+                cnt[i] = orc_min(num[i], (1 + is4) << 1);
+                for (int c = 0; c < cnt[i]; c++)
+                    pos[i][c] = start + c * step;
+            }
+        }
+    }
+    if (have) {
+        int sel[3][8] = { { 0 } };
+        const ptrdiff_t lo = (ptrdiff_t)j->y0 * ls + j->x0;
+#define LP(off) orc_ld(luma, (off), wide)
+        for (int i = 0; i < cnt[0]; i++) {                        /* top luma */
+            if (!hs && !vs) { sel[0][i] = LP(lo - avail_t * ls + pos[0][i]); continue; }
+            const int xx = pos[0][i] << hs;
+            const int has_left = xx || avail_l;
+            if (vs && !j->ctu_boundary) {
+                const ptrdiff_t o = lo - 2 * ls + xx;
+                const int l = has_left ? LP(o - 1) : LP(o);
+                if (j->collocated)
+                    sel[0][i] = (LP(o - ls) + l + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+                else {
+                    const int l1 = has_left ? LP(o - 1 + ls) : LP(o + ls);
+                    sel[0][i] = (l + l1 + 2 * (LP(o) + LP(o + ls)) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+                }
+            } else {
+                const ptrdiff_t o = lo - ls + xx;
+                const int l = has_left ? LP(o - 1) : LP(o);
+                sel[0][i] = (l + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+            }
+        }
+        for (int i = 0; i < cnt[1]; i++) {                        /* left luma */
+            if (!hs && !vs) { sel[0][cnt[0] + i] = LP(lo - avail_l + (ptrdiff_t)pos[1][i] * ls); continue; }
+            const int yy = pos[1][i] << vs;
+            const ptrdiff_t o = lo - (1 + hs) * avail_l + (ptrdiff_t)yy * ls, l = o - avail_l;
+            int p;
+            if (!vs)
+                p = (LP(l) + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+            else if (j->collocated) {
+                const int t = (yy || avail_t) ? LP(o - ls) : LP(o);
+                p = (LP(l) + t + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+            } else
+                p = (LP(l) + LP(l + ls) + 2 * LP(o) + 2 * LP(o + ls) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+            sel[0][cnt[0] + i] = p;
+        }
+#undef LP
+        for (int c = 0; c < 2; c++) {                             /* chroma neighbours :171 */
+            for (int i = 0; i < cnt[0]; i++)
+                sel[c + 1][i] = orc_ld(cpl[c], (ptrdiff_t)(y - 1) * cs[c] + x + pos[0][i], wide);
+            for (int i = 0; i < cnt[1]; i++)
+                sel[c + 1][cnt[0] + i] = orc_ld(cpl[c], (ptrdiff_t)(y + pos[1][i]) * cs[c] + x - 1, wide);
+        }
+        if (cnt[0] + cnt[1] == 2)
+            for (int c = 0; c < 3; c++) {
+                sel[c][3] = sel[c][0]; sel[c][2] = sel[c][1]; sel[c][0] = sel[c][1]; sel[c][1] = sel[c][3];
+            }
+        int mn[2] = { 0, 2 }, mx[2] = { 1, 3 }, t;
+#define SWAP(p, q) do { t = p; p = q; q = t; } while (0)
+        if (sel[0][mn[0]] > sel[0][mn[1]]) SWAP(mn[0], mn[1]);
+        if (sel[0][mx[0]] > sel[0][mx[1]]) SWAP(mx[0], mx[1]);
+        if (sel[0][mn[0]] > sel[0][mx[1]]) { SWAP(mn[0], mx[0]); SWAP(mn[1], mx[1]); }
+        if (sel[0][mn[1]] > sel[0][mx[0]]) SWAP(mn[1], mx[0]);
+#undef SWAP
+        int vmax[3], vmin[3];
+        for (int c = 0; c < 3; c++) {
+            vmax[c] = (sel[c][mx[0]] + sel[c][mx[1]] + 1) >> 1;
+            vmin[c] = (sel[c][mn[0]] + sel[c][mn[1]] + 1) >> 1;
+        }
+        const int diff = vmax[0] - vmin[0];
+        for (int i = 0; i < 2; i++) {
+            if (!diff) { a[i] = k[i] = 0; b[i] = vmin[i + 1]; continue; }
+            static const int div_sig[16] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 };
+            const int diffc = vmax[i + 1] - vmin[i + 1];
+            int xl = orc_log2(diff);
+            const int norm = ((diff << 4) >> xl) & 15;
+            xl += norm ? 1 : 0;
+            const int yl = orc_abs(diffc) > 0 ? orc_log2(orc_abs(diffc)) + 1 : 0;
+            const int v = div_sig[norm] | 8;
+            a[i] = (diffc * v + ((1 << yl) >> 1)) >> yl;
+            k[i] = orc_max(1, 3 + xl - yl);
+            if (3 + xl - yl < 1)
+                a[i] = orc_sign(a[i]) * 15;
+            b[i] = vmin[i + 1] - ((a[i] * vmin[0]) >> k[i]);
+        }
+    }
+    /* --- linear model on the down-sampled luma (:29); the reference keeps dsy in a pixel-typed array */
+    for (int yy = 0; yy < h; yy++)
+        for (int xx = 0; xx < w; xx++) {
+            const int dsy = cclm_ds_luma(j, wide, xx, yy);
+            for (int c = 0; c < 2; c++)
+                orc_st(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, orc_clip_px(((dsy * a[c]) >> k[c]) + b[c], bd), wide);
+        }
+}
+
+/* ------------------------------------------------------------------ LMCS chroma residual scaling, flattened (:390-446) */
+
+ORC_API int orc_lmcs_chroma_scale_flat(int bd, const orc_lmcs_scale_job *j)
+{
+    const int wide = bd > 8;
+    const uint8_t *luma = (const uint8_t *)(uintptr_t)j->luma;
+    const ptrdiff_t s = j->luma_stride >> wide;
+    const int size = j->size_y, x = j->x_vpdu, y = j->y_vpdu;
+    int cnt = 0, sum = 0;
+    if (j->avail_l) {
+        const int n = orc_min(j->pic_h - y, size);
+        for (int i = 0; i < n; i++) sum += orc_ld(luma, (ptrdiff_t)(y + i) * s + x - 1, wide);
+        sum += orc_ld(luma, (ptrdiff_t)(y + n - 1) * s + x - 1, wide) * (size - n);
+        cnt = size;
+    }
+    if (j->avail_t) {
+        const int n = orc_min(j->pic_w - x, size);
+        for (int i = 0; i < n; i++) sum += orc_ld(luma, (ptrdiff_t)(y - 1) * s + x + i, wide);
+        sum += orc_ld(luma, (ptrdiff_t)(y - 1) * s + x + n - 1, wide) * (size - n);
+        cnt += size;
+    }
+    const int avg = cnt ? (sum + (cnt >> 1)) >> orc_log2(cnt) : 1 << (bd - 1);
+    int i;
+    for (i = j->min_bin_idx; i <= j->max_bin_idx; i++)
+        if (avg < j->pivot[i + 1])
+            break;
+    return j->chroma_scale_coeff[orc_min(i, 15)];
+}
+
+ORC_API void orc_lmcs_scale_chroma_flat(int bd, const orc_lmcs_scale_job *j, int *dst, const int *coeff, int width, int height)
+{
+    const int scale = orc_lmcs_chroma_scale_flat(bd, j);
+    for (int i = 0; i < width * height; i++) {
+        const int c = orc_clip_intp2(coeff[i], bd);
+        dst[i] = c > 0 ? (c * scale + (1 << 10)) >> 11 : -((-c * scale + (1 << 10)) >> 11);
+    }
+}

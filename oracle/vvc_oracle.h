@@ -108,6 +108,26 @@ typedef struct orc_intra_job {
     uint8_t  pad_[6];
 } orc_intra_job;
 void orc_intra_pred_flat(int bd, const orc_intra_job *job);
+/* intra_cclm_pred / lmcs_scale_chroma flattened; same layouts as vvc355_cclm_job / vvc355_lmcs_scale_job */
+typedef struct orc_cclm_job {
+    uint64_t luma, cb, cr;
+    int32_t  luma_stride, cb_stride, cr_stride;
+    int16_t  x0, y0, width, height;
+    int16_t  top_avail_c, left_avail_c;
+    uint8_t  mode, hs, vs, avail_t, avail_l, collocated, ctu_boundary, pad_;
+} orc_cclm_job;
+typedef struct orc_lmcs_scale_job {
+    uint64_t luma;
+    int32_t  luma_stride;
+    int16_t  x_vpdu, y_vpdu, pic_w, pic_h, size_y;
+    uint8_t  avail_t, avail_l, min_bin_idx, max_bin_idx;
+    uint16_t pivot[17];
+    uint16_t chroma_scale_coeff[16];
+    uint16_t pad_[6];
+} orc_lmcs_scale_job;
+void orc_intra_cclm_pred_flat(int bd, const orc_cclm_job *job);
+int  orc_lmcs_chroma_scale_flat(int bd, const orc_lmcs_scale_job *job);
+void orc_lmcs_scale_chroma_flat(int bd, const orc_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height);
 int  orc_intra_pred_angle(int mode);
 int  orc_intra_inv_angle(int angle);
 int  orc_intra_nscale(int w, int h, int mode);
