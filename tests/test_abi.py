@@ -17,17 +17,21 @@ def declared_symbols():
     return names
 
 
+HOST_SYMBOLS = {"ff_vvc_dsp_init_mi355", "vvc355_dsp_count_slots", "vvc355_dsp_table_selftest"}
+
+
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(abi.LIB_PATH)
+    host = ctypes.CDLL(os.path.join(ROOT, "ffvvc_amd", "libvvc_mi355_host.so"))
     names = declared_symbols()
-    assert len(names) > 10
-    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert len(names) > 60
+    missing = [n for n in sorted(names) if not hasattr(host if n in HOST_SYMBOLS else lib, n)]
     assert not missing, f"declared in include/ but not exported: {missing}"
 
 
 def test_python_binding_covers_every_declared_symbol():
     bound = {"vvc355_" + k for t in (abi.SLOT_SIGNATURES, abi.RUNTIME_SIGNATURES, abi.BATCH_SIGNATURES, abi.FLAT_SIGNATURES) for k in t}
-    names = {n for n in declared_symbols() if n.startswith("vvc355_")}
+    names = {n for n in declared_symbols() if n.startswith("vvc355_")} - HOST_SYMBOLS
     assert names == bound, f"only in header: {sorted(names - bound)}; only in binding: {sorted(bound - names)}"
 
 
