@@ -24,7 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ffvvc_amd import abi, batch  # noqa: E402
+from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -215,10 +215,7 @@ def main():
                 st.launch(stream)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.barrier(dist, world, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         run_step()
@@ -230,10 +227,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cuda")
 
     if rank == 0:
         dom = next(st for st in chain if st.name == DOMINANT)

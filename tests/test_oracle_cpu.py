@@ -1,0 +1,171 @@
+"""CPU: properties of the oracle that hold independently of both implementations (the oracle is parity-unpinned — the
+reference cannot be built here and its tests hold no golden vectors — so these are the strongest checks available):
+transform-matrix identities, DC gains on flat input, identity cases, mode-helper tables."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import P, px_dtype, rand_pixels
+
+
+def table(orc, name, ctype, shape):
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array((ctype * n).in_dll(orc, "orc_tab_" + name)).reshape(shape).astype(np.int64)
+
+
+def inv_matrix(orc, ttype, n, nz=None):
+    """Matrix M with out = M @ in realised by orc_inv_tx_1d (column k = response to unit input k)."""
+    orc.orc_inv_tx_1d.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_size_t]
+    m = np.zeros((n, n), np.int64)
+    for k in range(n):
+        v = np.zeros(n, np.int32)
+        v[k] = 1
+        orc.orc_inv_tx_1d(ttype, n, P(v), 1, n if nz is None else nz)
+        m[:, k] = v
+    return m
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32])
+def test_dct2_matrix_is_near_orthogonal_and_nested(orc, n):
+    m = inv_matrix(orc, 0, n)
+    gram = m.T @ m                       # basis functions are the columns' duals: M = T^T, T T^T ~ 64^2 * n * I
+    diag = np.diag(gram)
+    assert np.all(np.abs(diag - 64 * 64 * n) <= 64 * 64 * n * 0.01)
+    off = gram - np.diag(diag)
+    assert np.max(np.abs(off)) <= 64 * 64 * n * 0.01
+    assert np.all(m[:, 0] == 64)         # DC basis
+    if n >= 4:                           # even basis functions of size n are the size n/2 basis, mirrored
+        half = inv_matrix(orc, 0, n // 2)
+        assert np.array_equal(m[: n // 2, 0::2], half)
+        assert np.array_equal(m[n // 2:, 0::2][::-1], half)
+
+
+def test_dct2_64_reads_only_32_inputs_and_gates_by_nz(orc):
+    m = inv_matrix(orc, 0, 64)
+    assert np.all(m[:, 32:] == 0) and np.all(m[:, :32] != 0)
+    gram = m[:, :32].T @ m[:, :32]
+    assert np.max(np.abs(gram - np.diag(np.diag(gram)))) <= 64 * 64 * 64 * 0.01
+    # nz gating: input k contributes iff k < 2 or nz > 2^floor(log2 k) (vvc_itx_1d.c:64-67)
+    for nz in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32):
+        g = inv_matrix(orc, 0, 32, nz)
+        used = [k for k in range(32) if np.any(g[:, k])]
+        want = [k for k in range(32) if k < 2 or nz > (1 << int(np.log2(k)))]
+        assert used == want, (nz, used)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_dst7_dct8_tables(orc, n):
+    dst7 = table(orc, f"dst7_{n}", ctypes.c_int8, (n, n))
+    dct8 = table(orc, f"dct8_{n}", ctypes.c_int8, (n, n))
+    # closed forms of the real-valued transforms, scaled like the standard's integer matrices
+    k, j = np.mgrid[0:n, 0:n]
+    s7 = np.sqrt(4.0 / (2 * n + 1)) * np.sin(np.pi * (2 * k + 1) * (j + 1) / (2 * n + 1)) * 64 * np.sqrt(n)
+    c8 = np.sqrt(4.0 / (2 * n + 1)) * np.cos(np.pi * (2 * k + 1) * (2 * j + 1) / (4 * n + 2)) * 64 * np.sqrt(n)
+    assert np.max(np.abs(dst7 - s7)) <= 1.5
+    assert np.max(np.abs(dct8 - c8)) <= 1.5
+    assert np.array_equal(dct8, ((-1) ** k) * dst7[:, ::-1])
+    g = dst7 @ dst7.T
+    assert np.max(np.abs(g - np.diag(np.diag(g)))) <= 64 * 64 * n * 0.02
+
+
+def test_itx_dc_response_and_zero(orc):
+    orc.orc_itx.restype = ctypes.c_int
+    for lw in range(1, 7):
+        for lh in range(1, 7):
+            w, h = 1 << lw, 1 << lh
+            c = np.zeros((h, w), np.int32)
+            assert orc.orc_itx(0, 0, lw, lh, P(c), 1, 1, 15, 10) == 0 and not c.any()
+            c[0, 0] = 1 << 12
+            assert orc.orc_itx(0, 0, lw, lh, P(c), 1, 1, 15, 10) == 0
+            # a DC coefficient reconstructs to a flat block: 64*64*c / 2^(7 + 5 + 15 - 10)
+            assert np.all(c == c[0, 0]) and abs(int(c[0, 0]) - (64 * 64 * (1 << 12) >> 17)) <= 1
+    assert orc.orc_itx(1, 0, 1, 1, P(np.zeros(4, np.int32)), 1, 1, 15, 10) == -1     # DST7 has no 2-point form
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_interpolation_filters_have_unit_dc_gain(orc, bd):
+    luma = table(orc, "inter_luma_filters", ctypes.c_int8, (3, 16, 8))
+    chroma = table(orc, "inter_chroma_filters", ctypes.c_int8, (3, 32, 4))
+    assert np.all(luma.sum(axis=2) == 64) and np.all(chroma.sum(axis=2) == 64)
+    fl = table(orc, "intra_luma_filter", ctypes.c_int8, (2, 32, 4))
+    assert np.all(fl.sum(axis=2) == 64)
+    # flat picture in -> the same flat value out of put_uni for every fraction
+    val = (1 << bd) * 3 // 5
+    plane = np.full((48, 64), val, px_dtype(bd))
+    ps = plane.itemsize
+    for chroma_flag, tab in ((0, luma), (1, chroma)):
+        for ph in (1, tab.shape[1] // 2, tab.shape[1] - 1):
+            f = np.ascontiguousarray(tab[0, ph].astype(np.int8))
+            for vfrac in (0, 1):
+                for hfrac in (0, 1):
+                    dst = np.zeros((16, 16), plane.dtype)
+                    orc.orc_put_uni(bd, chroma_flag, vfrac, hfrac, P(dst), 16 * ps, P(plane, 8 * 64 + 8), 64 * ps, 16, P(f), P(f), 16)
+                    assert np.all(dst == val)
+                    d16 = np.zeros((16, 128), np.int16)
+                    orc.orc_put(bd, chroma_flag, vfrac, hfrac, P(d16), P(plane, 8 * 64 + 8), 64 * ps, 16, P(f), P(f), 16)
+                    assert np.all(d16[:, :16] == val << (14 - bd))
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_filters_leave_flat_pictures_flat(orc, bd):
+    rng = np.random.default_rng(bd)
+    val = (1 << bd) // 3
+    src = np.full((160, 176), val, px_dtype(bd))
+    ps = src.itemsize
+    off = 8 * 176 + 8
+    # ALF: every tap difference is zero, whatever the coefficients
+    coeff = rng.integers(-128, 128, size=(1024, 12)).astype(np.int16)
+    clip = np.full((1024, 12), 1 << bd, np.int16)
+    dst = np.zeros((128, 128), src.dtype)
+    orc.orc_alf_filter_luma(bd, P(dst), 128 * ps, P(src, off), 176 * ps, 128, 128, P(coeff), P(clip), 124)
+    assert np.all(dst == val)
+    # classification of a flat block: no activity, no direction
+    cls = np.full(1024, -1, np.int32); tr = np.full(1024, -1, np.int32)
+    grad = np.zeros(66 * 66 * 4, np.int32)
+    orc.orc_alf_classify(bd, P(cls), P(tr), P(src, off), 176 * ps, 128, 128, 124, P(grad))
+    assert np.all(cls == 0) and np.all(tr == 3)
+    # SAO edge: all neighbours equal -> category 0 offset (index 0 of the table)
+    offs = np.array([5, 1, 2, 3, 4], np.int16)
+    ess = 320 // ps                                   # implicit source stride of 320 bytes
+    edge_src = np.full((40, ess), val, src.dtype)
+    d = np.zeros((32, 32), src.dtype)
+    orc.orc_sao_edge_filter(bd, P(d), P(edge_src, 2 * ess + 8), 32 * ps, P(offs), 2, 32, 32)
+    assert np.all(d == val + 5)
+    # deblocking a flat edge changes nothing
+    img = np.full((24, 24), val, src.dtype)
+    beta = np.array([40, 40, 0, 0], np.int32); tc = np.array([20, 20, 0, 0], np.int32)
+    z = np.zeros(4, np.uint8); l7 = np.full(4, 7, np.uint8)
+    orc.orc_lf_filter_luma(bd, 1, P(img, 8 * 24 + 12), 24 * ps, P(beta), P(tc), P(z), P(z), P(l7), P(l7), 0)
+    assert np.all(img == val)
+    # planar / DC prediction from flat references
+    top = np.full(300, val, src.dtype); left = np.full(300, val, src.dtype)
+    for name in ("orc_pred_planar", "orc_pred_dc"):
+        blk = np.zeros((16, 32), src.dtype)
+        getattr(orc, name)(bd, P(blk), P(top, 100), P(left, 100), 32, 16, 32)
+        assert np.all(blk == val)
+
+
+def test_intra_mode_helpers(orc):
+    orc.orc_intra_pred_angle.restype = ctypes.c_int
+    orc.orc_intra_inv_angle.restype = ctypes.c_int
+    angles = [0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512]
+    assert orc.orc_intra_pred_angle(50) == 0 and orc.orc_intra_pred_angle(18) == 0
+    assert orc.orc_intra_pred_angle(66) == 32 and orc.orc_intra_pred_angle(2) == 32 and orc.orc_intra_pred_angle(34) == -32
+    assert orc.orc_intra_pred_angle(80) == 512 and orc.orc_intra_pred_angle(-14) == 512
+    for a in angles[1:]:
+        for s in (1, -1):
+            # the reference computes ROUND((float)(32 * 512.0 / angle)) (vvc_intra.c:683-690)
+            f = np.float32(16384.0 / (s * a))
+            want = int(-(-float(f) + 0.5)) if f < 0 else int(float(f) + 0.5)
+            assert orc.orc_intra_inv_angle(s * a) == want, a
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_avg_of_equal_predictions_is_identity(orc, bd):
+    rng = np.random.default_rng(3)
+    px = rand_pixels(rng, (8, 128), bd)
+    s = (px.astype(np.int32) << (14 - bd)).astype(np.int16)
+    d = np.zeros((8, 16), px.dtype)
+    orc.orc_avg(bd, P(d), 16 * d.itemsize, P(s), P(s), 16, 8)
+    assert np.array_equal(d, px[:, :16])
