@@ -88,3 +88,26 @@ def alf_luma_jobs(dst_ptr, src_ptr, pitch, itemsize, width, height, ctb, per_ctb
             j.ext_r, j.ext_b = min(3, width - x0 - w), min(3, height - y0 - h)
             j.coeff, j.clip, j.class_to_filt = per_ctb(rx, ry)
     return arr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Vectorised job builders (numpy structured arrays laid out like the C job structs) for whole-frame batches.
+
+def job_array(struct_cls, n: int) -> np.ndarray:
+    """Zeroed array of n job descriptors with the exact C layout of `struct_cls` (a ctypes.Structure)."""
+    return np.zeros(n, dtype=np.dtype(struct_cls, align=True))
+
+
+def ctb_grid(width: int, height: int, ctb: int):
+    """(x0, y0, w, h) of every CTB of a width x height plane, raster order (partial CTBs at the right / bottom edge)."""
+    xs, ys = np.arange(0, width, ctb), np.arange(0, height, ctb)
+    x0, y0 = np.meshgrid(xs, ys)
+    x0, y0 = x0.ravel(), y0.ravel()
+    return x0, y0, np.minimum(ctb, width - x0), np.minimum(ctb, height - y0)
+
+
+def block_grid(width: int, height: int, bw: int, bh: int):
+    """Origins of every full bw x bh block of the plane (the plane is assumed to be a multiple of the block size)."""
+    xs, ys = np.arange(0, width - bw + 1, bw), np.arange(0, height - bh + 1, bh)
+    x0, y0 = np.meshgrid(xs, ys)
+    return x0.ravel(), y0.ravel()

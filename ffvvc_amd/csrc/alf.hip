@@ -29,10 +29,20 @@ __device__ static const uint8_t kAlfPerm[4][12] = {       // vvc_filter_template
 };
 __device__ static const uint8_t kAlfVarTab[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
 // luma diamond taps (dy, dx), paired with (-dy, -dx): vvc_filter_template.c:102-113
-__device__ static const int8_t kLumaTap[12][2] = {
+__device__ static constexpr int8_t kLumaTap[12][2] = {
     { 3, 0 }, { 2, 1 }, { 2, 0 }, { 2, -1 }, { 1, 2 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 1, -2 }, { 0, 3 }, { 0, 2 }, { 0, 1 },
 };
 __device__ static const int8_t kChromaTap[6][2] = { { 2, 0 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 0, 2 }, { 0, 1 } };
+
+// clamp(x, -c, c) in one VALU op (the compiler cannot prove -c <= c, so it would emit max + min)
+__device__ __forceinline__ int clamp_sym(int x, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(-c), "v"(c));
+    return r;
+}
+// acc + f * p with 24-bit operands (full-rate v_mad_i32_i24; f is an int16 coefficient, |p| <= 2^(bd+1))
+__device__ __forceinline__ int mad24(int f, int p, int acc) { return __mul24(f, p) + acc; }
 
 // rows between row y and the virtual boundary on y's own side (0 = adjacent): taps fold to min(k, dist)
 __device__ __forceinline__ int vb_dist(int y, int vb_pos) { return y < vb_pos ? vb_pos - 1 - y : y - vb_pos; }
@@ -121,17 +131,18 @@ __device__ __forceinline__ void classify_win(const Win &w, int yb, int vb_pos, i
         const bool fold_dn = yy == vb_pos;        // B's lower neighbour row replaced by B's row
         const bool fold_up = yy == vb_pos + 2;    // A's upper neighbour row replaced by A's row
         const int ra = 1 + 2 * i, rb = ra + 1;
-        int g[4] = { 0, 0, 0, 0 };
+        unsigned g[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int ca = 2 + 2 * j, cb = ca + 1;
             const int a2 = w.at(ra, ca) << 1, b2 = w.at(rb, cb) << 1;
 #define UPA(c) (fold_up ? w.at(ra, c) : w.at(ra - 1, c))
 #define DNB(c) (fold_dn ? w.at(rb, c) : w.at(rb + 1, c))
-            g[0] += abs(a2 - UPA(ca) - w.at(rb, ca)) + abs(b2 - w.at(ra, cb) - DNB(cb));
-            g[1] += abs(a2 - w.at(ra, ca - 1) - w.at(ra, ca + 1)) + abs(b2 - w.at(rb, cb - 1) - w.at(rb, cb + 1));
-            g[2] += abs(a2 - UPA(ca - 1) - w.at(rb, ca + 1)) + abs(b2 - w.at(ra, cb - 1) - DNB(cb + 1));
-            g[3] += abs(a2 - UPA(ca + 1) - w.at(rb, ca - 1)) + abs(b2 - w.at(ra, cb + 1) - DNB(cb - 1));
+            // |2p - n1 - n2| accumulated with one v_sad_u32 per term (all operands are non-negative)
+            g[0] = __sad(a2, UPA(ca) + w.at(rb, ca), __sad(b2, w.at(ra, cb) + DNB(cb), g[0]));
+            g[1] = __sad(a2, w.at(ra, ca - 1) + w.at(ra, ca + 1), __sad(b2, w.at(rb, cb - 1) + w.at(rb, cb + 1), g[1]));
+            g[2] = __sad(a2, UPA(ca - 1) + w.at(rb, ca + 1), __sad(b2, w.at(ra, cb - 1) + DNB(cb + 1), g[2]));
+            g[3] = __sad(a2, UPA(ca + 1) + w.at(rb, ca - 1), __sad(b2, w.at(ra, cb + 1) + DNB(cb - 1), g[3]));
 #undef UPA
 #undef DNB
         }
@@ -140,6 +151,38 @@ __device__ __forceinline__ void classify_win(const Win &w, int yb, int vb_pos, i
         }
     }
     block_class<BD>(sum, ac, cls, tr);
+}
+
+// 7x7 diamond on one 4x4 block entirely from the register window.  KIND 0: no virtual boundary nearby; KIND 1: the block's
+// last row is adjacent to the boundary from above (row i is 3 - i rows away); KIND 2: its first row is adjacent from below
+// (row i is i rows away).  Tap rows fold to min(dy, dist) and the adjacent row uses the >> 10 rounding (:76-96,:115-118);
+// everything is a compile-time index, so the window stays in registers.
+template <int BD, int KIND>
+__device__ __forceinline__ void filter_block_regs(const Win &win, const int (&f)[12], const int (&c)[12], uint8_t *drow, int dst_stride)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dist = KIND == 0 ? 3 : KIND == 1 ? 3 - i : i;
+        int out[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r0 = 3 + i, c0 = 4 + j;
+            const int cur = win.at(r0, c0);
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int dy = kLumaTap[k][0] < dist ? kLumaTap[k][0] : dist, dx = kLumaTap[k][1];
+                const int a = win.at(r0 + dy, c0 + dx), b = win.at(r0 - dy, c0 - dx);
+                sum = mad24(f[k], clamp_sym(a - cur, c[k]) + clamp_sym(b - cur, c[k]), sum);
+            }
+            out[j] = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+        }
+        uint8_t *d = drow + (ptrdiff_t)i * dst_stride;
+        if (BD > 8)
+            *(uint2 *)d = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+        else
+            *(uint32_t *)d = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- luma kernel
@@ -151,12 +194,26 @@ template <int BD, int MODE>
 __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__restrict__ jobs)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
+    // fused mode: the CTB's filter set, expanded for the 4 transposes: [transpose][class][tap] = coeff | clip << 16
+    __shared__ __attribute__((aligned(16))) uint32_t ftab[MODE == 1 ? 4 * 25 * 12 : 4];
     const vvc355_alf_job job = jobs[blockIdx.x >> 2];
     const int y_base = (blockIdx.x & 3) * kStripH;
     if (y_base >= job.h)
         return;
     const int rows = min(kStripH, job.h - y_base);
     stage_tile<BD>(tile, job, y_base, rows, 3);
+    if (MODE == 1) {
+        // alf_recon_coeff_and_clip (:383) for every (transpose, class) once per workgroup
+        const int16_t *coeff_set = (const int16_t *)job.coeff;
+        const uint8_t *clip_idx = (const uint8_t *)job.clip, *c2f = (const uint8_t *)job.class_to_filt;
+        for (int e = threadIdx.x; e < 4 * 25 * 12; e += blockDim.x) {
+            const int t = e / 300, r = e - t * 300, cls = r / 12, k = r - cls * 12;
+            const int idx = kAlfPerm[t][k];
+            const int q = clip_idx[cls * 12 + idx];
+            const int cv = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
+            ftab[e] = (uint32_t)(uint16_t)coeff_set[c2f[cls] * 12 + idx] | ((uint32_t)cv << 16);
+        }
+    }
     __syncthreads();
 
     const int bx = threadIdx.x & 31, by = threadIdx.x >> 5;
@@ -187,44 +244,26 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
             ((int *)job.clip)[blk] = tr;
             return;
         }
-        // alf_recon_coeff_and_clip (:383) for this block
-        const int16_t *cs = (const int16_t *)job.coeff + ((const uint8_t *)job.class_to_filt)[cls] * 12;
-        const uint8_t *ci = (const uint8_t *)job.clip + cls * 12;
+        const uint4 *e = (const uint4 *)&ftab[(tr * 25 + cls) * 12];
+        const uint4 e0 = e[0], e1 = e[1], e2 = e[2];
+        const uint32_t ev[12] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w };
 #pragma unroll
         for (int k = 0; k < 12; k++) {
-            const int idx = kAlfPerm[tr][k];
-            const int q = ci[idx];
-            f[k] = cs[idx];
-            c[k] = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
+            f[k] = (int)(int16_t)(ev[k] & 0xffff);
+            c[k] = (int)(ev[k] >> 16);
         }
     }
 
     uint8_t *dst = (uint8_t *)job.dst;
     // rows of this block closer than 3 to the virtual boundary fold their taps: generic LDS path
     const bool near_vb = vb_dist(yb, vb_pos) < 3 || vb_dist(yb + 3, vb_pos) < 3 || (yb < vb_pos && yb + 3 >= vb_pos);
+    uint8_t *drow = dst + (ptrdiff_t)yb * job.dst_stride + x * (BD > 8 ? 2 : 1);
     if (!near_vb) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int out[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r0 = 3 + i, c0 = 4 + j;
-                const int cur = win.at(r0, c0);
-                int sum = 0;
-#pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    const int dy = kLumaTap[k][0], dx = kLumaTap[k][1];
-                    const int a = win.at(r0 + dy, c0 + dx), b = win.at(r0 - dy, c0 - dx);
-                    sum += f[k] * (clip3(a - cur, -c[k], c[k]) + clip3(b - cur, -c[k], c[k]));
-                }
-                out[j] = clip_px<BD>(((sum + 64) >> 7) + cur);
-            }
-            uint8_t *d = dst + (ptrdiff_t)(yb + i) * job.dst_stride;
-            if (BD > 8)
-                *(uint2 *)(d + x * 2) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
-            else
-                *(uint32_t *)(d + x) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-        }
+        filter_block_regs<BD, 0>(win, f, c, drow, job.dst_stride);
+    } else if (yb + 4 == vb_pos) {
+        filter_block_regs<BD, 1>(win, f, c, drow, job.dst_stride);      // the block row just above the boundary
+    } else if (yb == vb_pos) {
+        filter_block_regs<BD, 2>(win, f, c, drow, job.dst_stride);      // the block row just below it
     } else {
         for (int i = 0; i < 4; i++) {
             const int y = yb + i, dist = vb_dist(y, vb_pos);
