@@ -5,7 +5,7 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 
 ``python -m torch.distributed.run`` with one rank per GPU.  A *step* is one pass of every stage of the hot path over one
 synthetic 8K (7680x4320, 4:2:0, 10-bit) random-access frame = 2040 CTUs of 128x128, all inputs resident in HBM:
 
-    inter MC (8-tap luma / 4-tap chroma hv, two references) -> bi-pred average -> intra prediction (intra CTUs)
+    inter prediction (8-tap luma / 4-tap chroma hv from two references, averaged; fused) -> intra prediction (intra CTUs)
     -> inverse transform + residual add -> LMCS inverse luma map -> deblock (vertical, horizontal; luma + chroma)
     -> SAO -> ALF (luma classify+filter, chroma, cross-component)
 
@@ -112,62 +112,39 @@ def build_chain(lib, torch, fr):
     rec = fr.planes(False)                                               # prediction -> reconstruction -> deblocked
     sao = fr.planes(False)
     out = fr.planes(False)
-    tmp = [[fr.i16_plane(w, h) for (w, h) in fr.dims] for _ in range(2)]  # 14-bit intermediates of the two references
 
     # CTU kinds: 80 % inter (bi-pred), 20 % intra
     ctu_inter = rng.random(fr.n_ctus) < 0.8
 
-    # ---------------------------------------------------------------- inter MC: put x2 references, every component
-    mc_jobs = []
+    # ---------------------------------------------------------------- inter prediction: two references interpolated (8-tap luma /
+    # 4-tap chroma, hv) and averaged straight to pixels, one job per 16x16 luma / 8x8 chroma block of the inter CTUs
+    pj = []
     for c, (w, h) in enumerate(fr.dims):
         bs = 16 if c == 0 else 8
         cs = CTB if c == 0 else CTB // 2
         x0, y0 = batch.block_grid(w // bs * bs, h // bs * bs, bs, bs)
         inter = ctu_inter[(y0 // cs) * fr.ncx + (x0 // cs)]
         x0, y0 = x0[inter], y0[inter]
-        for r in range(2):
-            j = batch.job_array(abi.McJob, len(x0))
-            mvx, mvy = rng.integers(-24, 25, size=len(x0)), rng.integers(-24, 25, size=len(x0))
-            nph = 16 if c == 0 else 32
-            fx, fy = rng.integers(1, nph, size=len(x0)), rng.integers(1, nph, size=len(x0))
-            sp = fr.pitch(ref[r][c])
-            j["src"] = ptr(ref[r][c]) + (y0 + mvy + Frame.PAD) * sp + (x0 + mvx + Frame.PAD) * isz
-            j["src_stride"] = sp
-            j["dst"] = ptr(tmp[r][c]) + y0 * fr.pitch(tmp[r][c]) + x0 * 2
-            j["dst_stride"] = fr.pitch(tmp[r][c])
-            j["w"] = j["h"] = bs
-            tab = luma_tab if c == 0 else chroma_tab
-            ntap = 8 if c == 0 else 4
-            j["hf"][:, :ntap] = tab[0, fx]
-            j["vf"][:, :ntap] = tab[0, fy]
-            j["kind"], j["chroma"], j["hfrac"], j["vfrac"] = 0, int(c > 0), 1, 1
-            mc_jobs.append(j)
-    mc_all = np.concatenate(mc_jobs)
-    d_mc = fr.upload(mc_all.view(np.uint8))
-    n_mc = len(mc_all)
-    inter_samples = sum(int(len(j)) * int(j["w"][0]) ** 2 for j in mc_jobs) // 2        # per reference
-    chain.append(Stage("inter_mc_put", f"mc_kernel<{bd}>", lambda st: lib.vvc355_mc_batch(st, bd, ptr(d_mc), n_mc, 16, 16),
-                       inter_samples * 2 * (isz + 2)))      # read a reference sample, write an int16, two references
-
-    # ---------------------------------------------------------------- bi-pred average of the inter CTUs
-    bj = []
-    for c, (w, h) in enumerate(fr.dims):
-        cs = CTB if c == 0 else CTB // 2
-        x0, y0, cw, ch = batch.ctb_grid(w, h, cs)
-        x0, y0, cw, ch = x0[ctu_inter], y0[ctu_inter], cw[ctu_inter], ch[ctu_inter]
-        j = batch.job_array(abi.BlendJob, len(x0))
+        j = batch.job_array(abi.PredJob, len(x0))
         j["dst"] = ptr(rec[c]) + y0 * fr.pitch(rec[c]) + x0 * isz
         j["dst_stride"] = fr.pitch(rec[c])
-        for r, key in enumerate(("src0", "src1")):
-            j[key] = ptr(tmp[r][c]) + y0 * fr.pitch(tmp[r][c]) + x0 * 2
-            j[key + "_stride"] = fr.pitch(tmp[r][c])
-        j["w"], j["h"], j["mode"] = cw, ch, 0
-        bj.append(j)
-    blend_all = np.concatenate(bj)
-    d_blend = fr.upload(blend_all.view(np.uint8))
-    n_blend = len(blend_all)
-    chain.append(Stage("inter_bipred_avg", f"blend_kernel<{bd}>", lambda st: lib.vvc355_blend_batch(st, bd, ptr(d_blend), n_blend, CTB, CTB),
-                       inter_samples * (4 + isz)))
+        tab, nph, ntap = (luma_tab, 16, 8) if c == 0 else (chroma_tab, 32, 4)
+        for r, (sk, hk, vk) in enumerate((("src0", "hf0", "vf0"), ("src1", "hf1", "vf1"))):
+            mvx, mvy = rng.integers(-24, 25, size=len(x0)), rng.integers(-24, 25, size=len(x0))
+            sp = fr.pitch(ref[r][c])
+            j[sk] = ptr(ref[r][c]) + (y0 + mvy + Frame.PAD) * sp + (x0 + mvx + Frame.PAD) * isz
+            j[sk + "_stride"] = sp
+            j[hk][:, :ntap] = tab[0, rng.integers(1, nph, size=len(x0))]
+            j[vk][:, :ntap] = tab[0, rng.integers(1, nph, size=len(x0))]
+        j["w"] = j["h"] = bs
+        j["chroma"], j["frac"], j["mode"] = int(c > 0), 15, 0
+        pj.append(j)
+    pred_all = np.concatenate(pj)
+    d_pred = fr.upload(pred_all.view(np.uint8))
+    n_pred = len(pred_all)
+    inter_samples = sum(int(len(j)) * int(j["w"][0]) ** 2 for j in pj)
+    chain.append(Stage("inter_pred_bi", f"pred_fused_kernel<{bd}>", lambda st: lib.vvc355_pred_fused_batch(st, bd, ptr(d_pred), n_pred),
+                       inter_samples * 3 * isz))            # two reference samples read + one sample written
 
     # ---------------------------------------------------------------- intra prediction of the intra CTUs (16x16 luma, 8x8 chroma TUs)
     ij = []
@@ -196,6 +173,7 @@ def build_chain(lib, torch, fr):
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     tj = []
+    itx_launches = []          # (first job, count, log2 area): one launch per block size
     coeff_off = 0
     for c, (w, h) in enumerate(fr.dims):
         if c == 0:
@@ -226,6 +204,7 @@ def build_chain(lib, torch, fr):
             j["nzw"] = 1 + (rng.random(len(x0)) * lim_h).astype(np.int64)
             j["nzh"] = 1 + (rng.random(len(x0)) * lim_v).astype(np.int64)
             j["range"], j["bd"], j["store_coeffs"] = 15, bd, 0
+            itx_launches.append((sum(len(t) for t in tj), len(j), 2 * lg))
             tj.append(j)
     coeffs = torch.randint(-(1 << 12), 1 << 12, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32)
     fr.keep.append(coeffs)
@@ -234,8 +213,13 @@ def build_chain(lib, torch, fr):
     d_itx = fr.upload(itx_all.view(np.uint8))
     n_itx = len(itx_all)
     n_samples = coeff_off // 4
-    chain.append(Stage("itx_add_residual", f"itx_kernel<{bd}>", lambda st: lib.vvc355_itx_batch(st, bd, ptr(d_itx), n_itx),
-                       n_samples * (4 + 2 * isz)))
+    jsz = itx_all.dtype.itemsize
+
+    def launch_itx(st):
+        for (first, count, lg2) in itx_launches:
+            lib.vvc355_itx_batch(st, bd, ptr(d_itx) + first * jsz, count, lg2)
+
+    chain.append(Stage("itx_add_residual", f"itx_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz)))
 
     # ---------------------------------------------------------------- LMCS inverse luma mapping
     lut = fr.upload(np.sort(rng.integers(0, 1 << bd, size=1 << bd)).astype(np.uint8 if bd == 8 else np.uint16))

@@ -101,9 +101,10 @@ BATCH_SIGNATURES = {
     "sao_batch":        ("v", "pipiii"),
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
-    "itx_batch":        ("v", "pipi"),
+    "itx_batch":        ("v", "pipii"),
     "intra_pred_batch": ("v", "pipi"),
     "cclm_batch":       ("v", "pipi"),
+    "pred_fused_batch": ("v", "pipi"),
 }
 
 
@@ -238,4 +239,17 @@ class LmcsScaleJob(ctypes.Structure):
         ("size_y", ctypes.c_int16),
         ("avail_t", ctypes.c_uint8), ("avail_l", ctypes.c_uint8), ("min_bin_idx", ctypes.c_uint8), ("max_bin_idx", ctypes.c_uint8),
         ("pivot", ctypes.c_uint16 * 17), ("chroma_scale_coeff", ctypes.c_uint16 * 16), ("pad_", ctypes.c_uint16 * 6),
+    ]
+
+
+class PredJob(ctypes.Structure):
+    """Mirror of vvc355_pred_job."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("src0", ctypes.c_uint64), ("src1", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("src0_stride", ctypes.c_int32), ("src1_stride", ctypes.c_int32),
+        ("hf0", ctypes.c_int8 * 8), ("vf0", ctypes.c_int8 * 8), ("hf1", ctypes.c_int8 * 8), ("vf1", ctypes.c_int8 * 8),
+        ("w", ctypes.c_uint8), ("h", ctypes.c_uint8), ("chroma", ctypes.c_uint8), ("frac", ctypes.c_uint8),
+        ("mode", ctypes.c_uint8), ("pad0_", ctypes.c_uint8),
+        ("denom", ctypes.c_int16), ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
+        ("pad1_", ctypes.c_int16 * 2),
     ]

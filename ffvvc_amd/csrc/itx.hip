@@ -56,22 +56,39 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
     return (int)acc;
 }
 
-template <int BD>
-__global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs)
+// CLS 0: one wave per block of <= 64 coefficients (four blocks per workgroup, wave-level synchronisation only);
+// CLS 1: one 256-lane workgroup per block of <= 1024; CLS 2: <= 4096 (64x64).  Small blocks dominate real streams, so the
+// small classes keep their LDS footprint (and therefore the number of resident blocks per CU) proportionate.
+template <int BD, int CLS>
+__global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
 {
-    __shared__ int buf[64 * 64];
-    __shared__ int tmp[64 * 64];
+    // CLS 3: sixteen lanes per block of <= 16 coefficients (4x4 and smaller), sixteen blocks per workgroup
+    constexpr int CAP = CLS == 3 ? 16 : CLS == 0 ? 64 : CLS == 1 ? 1024 : 4096;
+    constexpr int NT = CLS == 3 ? 16 : CLS == 0 ? 64 : 256;          // lanes that share one block
+    constexpr int TBS = 256 / NT;                    // blocks per workgroup
+    __shared__ int buf_all[TBS][CAP];
+    __shared__ int tmp_all[TBS][CAP];
     __shared__ int8_t cos_lds[256];
-    const vvc355_itx_job job = jobs[blockIdx.x];
+#define ITX_SYNC()                                                                  \
+    do {                                                                            \
+        if (CLS == 0 || CLS == 3) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
+        else __syncthreads();                                                       \
+    } while (0)
+    cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
+    __syncthreads();
+    const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int ji = blockIdx.x * TBS + sub;
+    if (ji >= n_jobs)
+        return;                                      // whole waves (CLS 0) or the whole workgroup leave together
+    int *buf = buf_all[sub], *tmp = tmp_all[sub];
+    const vvc355_itx_job job = jobs[ji];
     const int w = 1 << job.log2_w, h = 1 << job.log2_h, n = w * h;
     const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
     int *coeffs = (int *)job.coeffs;
-    const int tid = threadIdx.x;
 
-    cos_lds[tid] = d_tab_dct2_cos[tid];
-    for (int i = tid; i < n; i += 256)
+    for (int i = tid; i < n; i += NT)
         buf[i] = coeffs[i];
-    __syncthreads();
+    ITX_SYNC();
 
     const bool dc_only = job.trh == TX_DCT2 && job.trv == TX_DCT2 && nzw == 1 && nzh == 1;
     int sh_final;
@@ -81,15 +98,15 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
         if (w == h && dc_only) {
             const int t = (buf[0] * 64 + (1 << (sh1 - 1))) >> sh1;
             const int dc = (t * 64 + (1 << (sh_final - 1))) >> sh_final;
-            __syncthreads();
-            for (int i = tid; i < n; i += 256)
+            ITX_SYNC();
+            for (int i = tid; i < n; i += NT)
                 buf[i] = dc;
             sh_final = -1;
         } else {
             // column pass on columns < nzw (vertical type, size h), then scale_clip; other columns become zero
             const int cnt = inputs_used(job.trv, h, nzh);
-            for (int o = tid; o < n; o += 256) {
-                const int y = o / w, x = o - y * w;
+            for (int o = tid; o < n; o += NT) {
+                const int y = o >> job.log2_w, x = o & (w - 1);
                 int v = 0;
                 if (x < nzw) {
                     v = inv_tx_out(job.trv, h, y, buf + x, w, cnt, cos_lds);
@@ -97,11 +114,11 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
                 }
                 tmp[o] = v;
             }
-            __syncthreads();
+            ITX_SYNC();
             // row pass (horizontal type, size w) with nz = nzw
             const int cnt2 = inputs_used(job.trh, w, nzw);
-            for (int o = tid; o < n; o += 256) {
-                const int y = o / w, x = o - y * w;
+            for (int o = tid; o < n; o += NT) {
+                const int y = o >> job.log2_w, x = o & (w - 1);
                 buf[o] = inv_tx_out(job.trh, w, x, tmp + y * w, 1, cnt2, cos_lds);
             }
         }
@@ -109,33 +126,34 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
         sh_final = 6 + range - bd;
         if (dc_only) {
             const int dc = (buf[0] * 64 + (1 << (sh_final - 1))) >> sh_final;
-            __syncthreads();
-            for (int i = tid; i < n; i += 256)
+            ITX_SYNC();
+            for (int i = tid; i < n; i += NT)
                 buf[i] = dc;
             sh_final = -1;
         } else {
             const int type = w > 1 ? job.trh : job.trv, nz = w > 1 ? nzw : nzh;
             const int cnt = inputs_used(type, n, nz);
-            for (int o = tid; o < n; o += 256)
+            for (int o = tid; o < n; o += NT)
                 tmp[o] = inv_tx_out(type, n, o, buf, 1, cnt, cos_lds);
-            __syncthreads();
-            for (int o = tid; o < n; o += 256)
+            ITX_SYNC();
+            for (int o = tid; o < n; o += NT)
                 buf[o] = tmp[o];
         }
     }
-    __syncthreads();
-    // final scale, then either store residuals in place (slot semantics) and/or add them to the prediction
+    ITX_SYNC();
+    // final scale, then store residuals in place (slot semantics) and/or add them to the prediction
     uint8_t *dst = (uint8_t *)job.dst;
-    for (int o = tid; o < n; o += 256) {
+    for (int o = tid; o < n; o += NT) {
         const int r = sh_final < 0 ? buf[o] : (buf[o] + (1 << (sh_final - 1))) >> sh_final;
         if (job.store_coeffs)
             coeffs[o] = r;
         if (dst) {
-            const int y = o / w, x = o - y * w;
+            const int y = o >> job.log2_w, x = o & (w - 1);
             uint8_t *row = dst + (ptrdiff_t)y * job.dst_stride;
             st_px<BD>(row, x, clip_px<BD>(ld_px<BD>(row, x) + r));
         }
     }
+#undef ITX_SYNC
 }
 
 // add_residual / add_residual_joint / pred_residual_joint (vvcdsp_template.c:32,48,65); job.src0 = int residuals,
@@ -207,10 +225,16 @@ using namespace vvc355;
 extern "C" {
 extern const uint8_t vvc355_tab_lfnst_tr_set_index[95];
 
-void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs)
+void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int max_log2_area)
 {
     if (n_jobs <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((itx_kernel<BD>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    hipStream_t st = (hipStream_t)stream;
+    VVC355_BD_DISPATCH(bd, {
+        if (max_log2_area <= 4)       hipLaunchKernelGGL((itx_kernel<BD, 3>), dim3((n_jobs + 15) / 16), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 6)  hipLaunchKernelGGL((itx_kernel<BD, 0>), dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 10) hipLaunchKernelGGL((itx_kernel<BD, 1>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
+        else                          hipLaunchKernelGGL((itx_kernel<BD, 2>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
+    });
     HIP_CHECK(hipGetLastError());
 }
 
@@ -227,7 +251,7 @@ int vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw
     job.nzw = (uint8_t)nzw; job.nzh = (uint8_t)nzh; job.range = (uint8_t)log2_transform_range; job.bd = (uint8_t)bit_depth;
     job.store_coeffs = 1;
     vvc355_itx_batch(call.stream(), (int)bit_depth == 8 || (int)bit_depth == 10 || (int)bit_depth == 12 ? (int)bit_depth : 10,
-                     call.upload(&job, 1), 1);
+                     call.upload(&job, 1), 1, log2_w + log2_h);
     return 0;
 }
 

@@ -242,7 +242,8 @@ typedef struct vvc355_itx_job {
     uint8_t  store_coeffs, pad_[3];
 } vvc355_itx_job;
 
-void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs);
+/* max_log2_area = max over the batch of log2_w + log2_h; it selects the lanes-per-block mapping (<= 6: a wave per block) */
+void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int max_log2_area);
 
 /* VVCItxDSPContext.itx[trh][trv][log2 w][log2 h] — vvcdsp.h:118, vvcdsp.c:94-195.  Returns -1 (nothing done) for a
  * combination the reference table leaves NULL (vvcdsp_template.c:142-159), else 0. */
@@ -331,6 +332,29 @@ void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, in
 /* synchronous forms: plane addresses are HOST addresses; pic_w/pic_h (luma samples) bound what is staged */
 void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h);
 void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height);
+
+/* ------------------------------------------------------------------ fused prediction stage (mc_fused.hip) */
+
+/*
+ * One prediction block of at most 16x16 samples (even width and height), predicted straight to pixels:
+ *   mode 0  bi-prediction, avg      = put[..] x2 + inter.avg      (vvc_inter.c:253-296, vvc_inter_template.c:25)
+ *   mode 1  bi-prediction, weighted = put[..] x2 + inter.w_avg    (vvc_inter_template.c:42; denom, w0, w1, o0, o1)
+ *   mode 2  uni-prediction          = put_uni[..]                 (h2656_inter_template.c:44-245)
+ *   mode 3  uni-prediction weighted = put_uni_w[..]               (w0 = wx, o0 = ox, denom)
+ * src0/src1 = DEVICE address of the integer-position sample of the block in each (edge-padded) reference plane.
+ * frac bits: 1 = horizontal fraction of ref 0, 2 = vertical of ref 0, 4 / 8 = the same for ref 1; hf/vf hold 8 luma
+ * taps or 4 chroma taps (chroma != 0).  Larger prediction blocks are split into such tiles by the job builder.
+ */
+typedef struct vvc355_pred_job {
+    uint64_t dst, src0, src1;
+    int32_t  dst_stride, src0_stride, src1_stride;      /* bytes */
+    int8_t   hf0[8], vf0[8], hf1[8], vf1[8];
+    uint8_t  w, h, chroma, frac, mode, pad0_;
+    int16_t  denom, w0, w1, o0, o1;
+    int16_t  pad1_[2];
+} vvc355_pred_job;
+
+void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_job *jobs_dev, int n_jobs);
 
 #ifdef __cplusplus
 }
