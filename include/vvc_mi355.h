@@ -336,7 +336,7 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 /* ------------------------------------------------------------------ fused prediction stage (mc_fused.hip) */
 
 /*
- * One prediction block of at most 16x16 samples (even width and height), predicted straight to pixels:
+ * One prediction block of at most 16x16 samples (width 2, 4, 8 or 16; height even), predicted straight to pixels:
  *   mode 0  bi-prediction, avg      = put[..] x2 + inter.avg      (vvc_inter.c:253-296, vvc_inter_template.c:25)
  *   mode 1  bi-prediction, weighted = put[..] x2 + inter.w_avg    (vvc_inter_template.c:42; denom, w0, w1, o0, o1)
  *   mode 2  uni-prediction          = put_uni[..]                 (h2656_inter_template.c:44-245)

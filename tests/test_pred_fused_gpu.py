@@ -26,7 +26,7 @@ def test_pred_fused_batch(dev, orc, bd):
     while y + 16 <= ph:
         x = 0
         while x + 16 <= pw:
-            w, h = int(rng.choice([2, 4, 8, 12, 16])), int(rng.choice([2, 4, 8, 12, 16]))
+            w, h = int(rng.choice([2, 4, 8, 16])), int(rng.choice([2, 4, 6, 8, 12, 16]))
             chroma = int(rng.integers(0, 2))
             mode = int(rng.integers(0, 4))
             frac = int(rng.integers(0, 16))
