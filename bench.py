@@ -476,10 +476,13 @@ def main():
         chain = [st for st in chain if st.name in args.only.split(",")]
     stream = torch.cuda.current_stream().cuda_stream
 
-    def run_step(events=None):
-        for st in chain:
+    # events are created before the timed region; inside it they are only recorded
+    pool = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chain] for _ in range(args.steps)]
+
+    def run_step(events=None, step=0):
+        for i, st in enumerate(chain):
             if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = pool[step][i]
                 e0.record()
                 st.launch(stream)
                 e1.record()
@@ -495,8 +498,8 @@ def main():
     barrier()
     events = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(events)
+    for k in range(args.steps):
+        run_step(events, k)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()

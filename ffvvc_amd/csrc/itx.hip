@@ -56,18 +56,18 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
     return (int)acc;
 }
 
-// CLS 0: one wave per block of <= 64 coefficients (four blocks per workgroup, wave-level synchronisation only);
+// CLS 0: one wave per block of <= 256 coefficients (four blocks per workgroup, wave-level synchronisation only);
 // CLS 1: one 256-lane workgroup per block of <= 1024; CLS 2: <= 4096 (64x64).  Small blocks dominate real streams, so the
 // small classes keep their LDS footprint (and therefore the number of resident blocks per CU) proportionate.
 template <int BD, int CLS>
 __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
 {
     // CLS 3: sixteen lanes per block of <= 16 coefficients (4x4 and smaller), sixteen blocks per workgroup
-    constexpr int CAP = CLS == 3 ? 16 : CLS == 0 ? 64 : CLS == 1 ? 1024 : 4096;
+    constexpr int CAP = CLS == 3 ? 16 : CLS == 0 ? 256 : CLS == 1 ? 1024 : 4096;
     constexpr int NT = CLS == 3 ? 16 : CLS == 0 ? 64 : 256;          // lanes that share one block
     constexpr int TBS = 256 / NT;                    // blocks per workgroup
-    __shared__ int buf_all[TBS][CAP];
-    __shared__ int tmp_all[TBS][CAP];
+    __shared__ __attribute__((aligned(16))) int buf_all[TBS][CAP];
+    __shared__ __attribute__((aligned(16))) int tmp_all[TBS][CAP];
     __shared__ int8_t cos_lds[256];
 #define ITX_SYNC()                                                                  \
     do {                                                                            \
@@ -86,8 +86,40 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
     int *coeffs = (int *)job.coeffs;
 
-    for (int i = tid; i < n; i += NT)
-        buf[i] = coeffs[i];
+    // I/O mapping: lane `tid` owns the PER consecutive elements starting at tid * PER (row-major), so coefficients move as
+    // 16-byte vectors and pixels as 8/16-byte row segments.  The prediction samples the residual is added to are requested
+    // together with the coefficients, long before they are needed (one memory round trip on the critical path, not two).
+    constexpr int PER = CAP / NT;                    // 1, 4, 4, 16
+    using px_t = typename Px<BD>::type;
+    uint8_t *dst = (uint8_t *)job.dst;
+    const int e0 = tid * PER;
+    const bool row_io = PER > 1 && w >= PER;         // the lane's elements sit in one row: vector pixel access
+    px_t pred[PER];
+    if (dst && e0 < n) {
+        if (row_io) {
+            const px_t *prow = (const px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+                pred[q] = prow[q];                   // contiguous, aligned to PER samples: merged into wide loads
+        } else {
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int o = e0 + q;
+                pred[q] = o < n ? ((const px_t *)(dst + (ptrdiff_t)(o >> job.log2_w) * job.dst_stride))[o & (w - 1)] : (px_t)0;
+            }
+        }
+    }
+    if (PER == 1) {
+        if (e0 < n)
+            buf[e0] = coeffs[e0];
+    } else {
+#pragma unroll
+        for (int c4 = 0; c4 < PER / 4; c4++) {
+            const int e = e0 + c4 * 4;
+            if (e < n)                               // n is a multiple of 4 for every block of >= 4 coefficients
+                *(int4 *)&buf[e] = *(const int4 *)&coeffs[e];
+        }
+    }
     ITX_SYNC();
 
     const bool dc_only = job.trh == TX_DCT2 && job.trv == TX_DCT2 && nzw == 1 && nzh == 1;
@@ -102,6 +134,63 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
             for (int i = tid; i < n; i += NT)
                 buf[i] = dc;
             sh_final = -1;
+        } else if (w >= 4 && h >= 4) {
+            // Register-tiled passes: every lane accumulates FOUR outputs that share the matrix entry, reading the four
+            // inputs as one 16-byte LDS vector, i.e. one LDS vector + one table byte + four multiply-adds per four products.
+            // Column pass: lane -> (row y, columns x0..x0+3); result stored transposed (tmp[x][y]) so that the row pass can
+            // do the same with lane -> (column x, rows y0..y0+3).
+            const int cnt = inputs_used(job.trv, h, nzh);
+            const int cnt2 = inputs_used(job.trh, w, nzw);          // the row pass reads columns < cnt2 (zero beyond nzw)
+            // 24-bit multiplies are exact when every input magnitude is below 2^23: always true for the clipped intermediates
+            // of the row pass (range <= 20), checked here for the coefficients (the decoder's dequantiser clips them to range)
+            bool small = true;
+            for (int i = tid; i < n; i += NT)
+                small &= (unsigned)(buf[i] + (1 << 23)) < (1u << 24);
+            const bool all_small = (CLS == 0 || CLS == 3) ? true : (bool)__syncthreads_and(small);
+            const bool fast1 = (CLS == 0 || CLS == 3) ? false : all_small;     // wave classes: keep the exact 32-bit multiply
+            const int gx = (cnt2 + 3) >> 2, lgh = job.log2_h;
+            const int8_t *mv = job.trv == TX_DCT2 ? nullptr : dxt_matrix(job.trv, h);
+            for (int g = tid; g < (gx << lgh); g += NT) {
+                const int y = g & (h - 1), x0 = (g >> lgh) << 2;
+                int acc[4] = { 0, 0, 0, 0 };
+                if (x0 < nzw) {
+                    const int ang = (2 * y + 1) * (64 >> lgh);
+                    int a = 0;
+                    for (int k = 0; k < cnt; k++) {
+                        const int m = mv ? (int)mv[k * h + y] : (int)cos_lds[a];
+                        a = (a + ang) & 255;
+                        const int4 v = *(const int4 *)&buf[k * w + x0];
+                        if (fast1) {
+                            acc[0] += __mul24(m, v.x); acc[1] += __mul24(m, v.y); acc[2] += __mul24(m, v.z); acc[3] += __mul24(m, v.w);
+                        } else {
+                            acc[0] += m * v.x; acc[1] += m * v.y; acc[2] += m * v.z; acc[3] += m * v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int x = x0 + q;
+                    if (x < w)
+                        tmp[x * h + y] = x < nzw ? clip_intp2((acc[q] + (1 << (sh1 - 1))) >> sh1, range) : 0;
+                }
+            }
+            ITX_SYNC();
+            const int8_t *mh = job.trh == TX_DCT2 ? nullptr : dxt_matrix(job.trh, w);
+            for (int g = tid; g < (n >> 2); g += NT) {
+                const int x = g & (w - 1), y0 = (g >> job.log2_w) << 2;
+                const int ang = (2 * x + 1) * (64 >> job.log2_w);
+                int acc[4] = { 0, 0, 0, 0 }, a = 0;
+                for (int k = 0; k < cnt2; k++) {
+                    const int m = mh ? (int)mh[k * w + x] : (int)cos_lds[a];
+                    a = (a + ang) & 255;
+                    const int4 v = *(const int4 *)&tmp[k * h + y0];
+                    acc[0] += __mul24(m, v.x); acc[1] += __mul24(m, v.y); acc[2] += __mul24(m, v.z); acc[3] += __mul24(m, v.w);
+                }
+                // the old contents of buf (the coefficients) are dead once every lane has left the column pass
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    buf[(y0 + q) * w + x] = acc[q];
+            }
         } else {
             // column pass on columns < nzw (vertical type, size h), then scale_clip; other columns become zero
             const int cnt = inputs_used(job.trv, h, nzh);
@@ -142,15 +231,41 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     }
     ITX_SYNC();
     // final scale, then store residuals in place (slot semantics) and/or add them to the prediction
-    uint8_t *dst = (uint8_t *)job.dst;
-    for (int o = tid; o < n; o += NT) {
-        const int r = sh_final < 0 ? buf[o] : (buf[o] + (1 << (sh_final - 1))) >> sh_final;
-        if (job.store_coeffs)
-            coeffs[o] = r;
+    if (e0 < n) {
+        int r[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int o = e0 + q;
+            r[q] = o < n ? (sh_final < 0 ? buf[o] : (buf[o] + (1 << (sh_final - 1))) >> sh_final) : 0;
+        }
+        if (job.store_coeffs) {
+            if (PER == 1) {
+                coeffs[e0] = r[0];
+            } else {
+#pragma unroll
+                for (int c4 = 0; c4 < PER / 4; c4++)
+                    if (e0 + c4 * 4 < n)
+                        *(int4 *)&coeffs[e0 + c4 * 4] = make_int4(r[c4 * 4], r[c4 * 4 + 1], r[c4 * 4 + 2], r[c4 * 4 + 3]);
+            }
+        }
         if (dst) {
-            const int y = o >> job.log2_w, x = o & (w - 1);
-            uint8_t *row = dst + (ptrdiff_t)y * job.dst_stride;
-            st_px<BD>(row, x, clip_px<BD>(ld_px<BD>(row, x) + r));
+            if (row_io) {
+                px_t *prow = (px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
+                px_t outv[PER];
+#pragma unroll
+                for (int q = 0; q < PER; q++)
+                    outv[q] = (px_t)clip_px<BD>((int)pred[q] + r[q]);
+#pragma unroll
+                for (int q = 0; q < PER; q++)
+                    prow[q] = outv[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < PER; q++) {
+                    const int o = e0 + q;
+                    if (o < n)
+                        st_px<BD>(dst + (ptrdiff_t)(o >> job.log2_w) * job.dst_stride, o & (w - 1), clip_px<BD>((int)pred[q] + r[q]));
+                }
+            }
         }
     }
 #undef ITX_SYNC
@@ -231,7 +346,7 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
     hipStream_t st = (hipStream_t)stream;
     VVC355_BD_DISPATCH(bd, {
         if (max_log2_area <= 4)       hipLaunchKernelGGL((itx_kernel<BD, 3>), dim3((n_jobs + 15) / 16), dim3(256), 0, st, jobs_dev, n_jobs);
-        else if (max_log2_area <= 6)  hipLaunchKernelGGL((itx_kernel<BD, 0>), dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 8)  hipLaunchKernelGGL((itx_kernel<BD, 0>), dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs_dev, n_jobs);
         else if (max_log2_area <= 10) hipLaunchKernelGGL((itx_kernel<BD, 1>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
         else                          hipLaunchKernelGGL((itx_kernel<BD, 2>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
     });
