@@ -168,7 +168,7 @@ def build_chain(lib, torch, fr):
     d_intra = fr.upload(intra_all.view(np.uint8))
     n_intra = len(intra_all)
     intra_samples = sum(int(len(j)) * int(j["w"][0]) ** 2 for j in ij)
-    chain.append(Stage("intra_pred", f"intra_pred_kernel<{bd}>", lambda st: lib.vvc355_intra_pred_batch(st, bd, ptr(d_intra), n_intra),
+    chain.append(Stage("intra_pred", f"intra_pred_kernel<{bd}>", lambda st: lib.vvc355_intra_pred_batch(st, bd, ptr(d_intra), n_intra, 8),
                        intra_samples * isz))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame

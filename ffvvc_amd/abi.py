@@ -102,7 +102,7 @@ BATCH_SIGNATURES = {
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipii"),
-    "intra_pred_batch": ("v", "pipi"),
+    "intra_pred_batch": ("v", "pipii"),
     "cclm_batch":       ("v", "pipi"),
     "pred_fused_batch": ("v", "pipi"),
 }

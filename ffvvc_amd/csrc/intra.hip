@@ -72,13 +72,20 @@ struct LRef {
     __device__ __forceinline__ int operator()(int i) const { return p[i]; }
 };
 
-// ------------------------------------------------------------------------------------------------ leaf predictors (whole workgroup)
+// ------------------------------------------------------------------------------------------------ leaf predictors
+// Executed by a group of NT lanes (a wave or the whole workgroup); `tid` is the lane's index in its group.
 
-template <int BD, typename R>
-__device__ void pred_planar(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h)
+template <int NT> __device__ __forceinline__ void group_sync()
+{
+    if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
+template <int BD, int NT, typename R>
+__device__ void pred_planar(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h)
 {
     const int lw = ilog2i(w), lh = ilog2i(h);
-    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    for (int i = tid; i < w * h; i += NT) {
         const int y = i / w, x = i - y * w;
         const int pv = ((h - 1 - y) * top(x) + (y + 1) * left(h)) << lw;
         const int ph = ((w - 1 - x) * left(y) + (x + 1) * top(w)) << lh;
@@ -86,29 +93,29 @@ __device__ void pred_planar(uint8_t *src, ptrdiff_t stride, R top, R left, int w
     }
 }
 
-template <int BD, typename R>
-__device__ void pred_dc(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int *scratch)
+template <int BD, int NT, typename R>
+__device__ void pred_dc(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int *scratch)
 {
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
         int sum = 0;
         if (w >= h) for (int i = 0; i < w; i++) sum += top(i);
         if (w <= h) for (int i = 0; i < h; i++) sum += left(i);
         *scratch = (sum + (int)(offset >> 1)) >> ilog2i((int)offset);
     }
-    __syncthreads();
+    group_sync<NT>();
     const int dc = *scratch, w4 = (w + 3) & ~3;          // stores cover whole groups of 4 (:856)
-    for (int i = threadIdx.x; i < w4 * h; i += blockDim.x) {
+    for (int i = tid; i < w4 * h; i += NT) {
         const int y = i / w4, x = i - y * w4;
         st_px<BD>(src, x + stride * y, dc);
     }
 }
 
-template <int BD, typename R>
-__device__ void pred_vh(uint8_t *src, ptrdiff_t stride, R ref, int w, int h, bool vertical)
+template <int BD, int NT, typename R>
+__device__ void pred_vh(int tid, uint8_t *src, ptrdiff_t stride, R ref, int w, int h, bool vertical)
 {
     const int ww = vertical ? w : (w + 3) & ~3;           // pred_h stores whole groups of 4 (:885)
-    for (int i = threadIdx.x; i < ww * h; i += blockDim.x) {
+    for (int i = tid; i < ww * h; i += NT) {
         const int y = i / ww, x = i - y * ww;
         st_px<BD>(src, x + stride * y, vertical ? ref(x) : ref(y));
     }
@@ -126,8 +133,8 @@ __device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx,
     return ((32 - fact) * ref(i + 1) + fact * ref(i + 2) + 16) >> 5;
 }
 
-template <int BD, typename R>
-__device__ void pred_angular(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, bool vertical,
+template <int BD, int NT, typename R>
+__device__ void pred_angular(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, bool vertical,
                              int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
 {
     const int angle = intra_pred_angle(mode);
@@ -137,7 +144,7 @@ __device__ void pred_angular(uint8_t *src, ptrdiff_t stride, R top, R left, int 
         nscale = intra_nscale(w, h, mode);
     }
     const int base = -(1 + ref_idx);
-    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    for (int i = tid; i < w * h; i += NT) {
         const int y = i / w, x = i - y * w;
         const int along = vertical ? x : y, across = vertical ? y : x;
         const int pos = (1 + ref_idx + across) * angle;
@@ -160,8 +167,8 @@ __device__ void pred_angular(uint8_t *src, ptrdiff_t stride, R top, R left, int 
 }
 
 // MIP (:708-824).  `red` = 16 ints of LDS scratch.
-template <int BD, typename R>
-__device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
+template <int BD, int NT, typename R>
+__device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
 {
     const int size_id = (w == 4 && h == 4) ? 0 : ((w == 4 || h == 4) || (w == 8 && h == 8)) ? 1 : 2;
     const int bsize = size_id == 0 ? 2 : 4, psize = size_id == 2 ? 8 : 4;
@@ -170,18 +177,18 @@ __device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, i
                           : size_id == 1 ? i_tab_mip_matrix_8x8 + mode_id * 16 * 8
                                          : i_tab_mip_matrix_16x16 + mode_id * 64 * 7;
     const int up_h = w / psize, up_v = h / psize;
-    __syncthreads();
-    if (threadIdx.x < 2 * bsize) {
+    group_sync<NT>();
+    if (tid < 2 * bsize) {
         // boundary down-sampling: first bsize entries from the top row (left column when transposed), then the other side
-        const int k = threadIdx.x, second = k >= bsize, from_top = second == (transposed != 0);
+        const int k = tid, second = k >= bsize, from_top = second == (transposed != 0);
         const int len = from_top ? w : h, per = len / bsize, i0 = (k - second * bsize) * per;
         int s = 0;
         for (int j = 0; j < per; j++)
             s += from_top ? top(i0 + j) : left(i0 + j);
         red[k] = per == 1 ? s : (s + (per >> 1)) >> ilog2i(per);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    group_sync<NT>();
+    if (tid == 0) {
         const int t0 = red[0];
         int ow, off = 1;
         if (size_id != 2) { off = 0; ow = (1 << (BD - 1)) - t0; }
@@ -191,9 +198,9 @@ __device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, i
         red[14] = 32 - 32 * ow;
         red[15] = t0;
     }
-    __syncthreads();
-    if (threadIdx.x < psize * psize) {
-        const int y = threadIdx.x / psize, x = threadIdx.x - y * psize;
+    group_sync<NT>();
+    if (tid < psize * psize) {
+        const int y = tid / psize, x = tid - y * psize;
         int p = 0;
         for (int i = 0; i < in_size; i++)
             p += red[i] * matrix[(y * psize + x) * in_size + i];
@@ -201,9 +208,9 @@ __device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, i
         const int cx = transposed ? y : x, cy = transposed ? x : y;
         st_px<BD>(src, (up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
     }
-    __syncthreads();
-    if (up_h > 1 && threadIdx.x < psize) {            // one lane per row that holds reduced samples
-        const int row = up_v - 1 + threadIdx.x * up_v;
+    group_sync<NT>();
+    if (up_h > 1 && tid < psize) {            // one lane per row that holds reduced samples
+        const int row = up_v - 1 + tid * up_v;
         int before = left(row);
         for (int j = 0; j < psize; j++) {
             const int after = ld_px<BD>(src, (j + 1) * up_h - 1 + stride * row);
@@ -212,9 +219,9 @@ __device__ void pred_mip(uint8_t *src, ptrdiff_t stride, R top, R left, int w, i
             before = after;
         }
     }
-    __syncthreads();
-    if (up_v > 1 && threadIdx.x < w) {                // one lane per column
-        const int x = threadIdx.x;
+    group_sync<NT>();
+    if (up_v > 1 && tid < w) {                // one lane per column
+        const int x = tid;
         int before = top(x);
         for (int j = 0; j < psize; j++) {
             const int after = ld_px<BD>(src, x + stride * ((j + 1) * up_v - 1));
@@ -239,27 +246,35 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
     __shared__ int scratch[16];
     GRef<BD> top{ a.top }, left{ a.left };
     switch (a.kind) {
-    case 0: pred_planar<BD>(a.src, a.stride, top, left, a.w, a.h); break;
-    case 1: pred_dc<BD>(a.src, a.stride, top, left, a.w, a.h, scratch); break;
-    case 2: pred_vh<BD>(a.src, a.stride, top, a.w, a.h, true); break;
-    case 3: pred_vh<BD>(a.src, a.stride, left, a.w, a.h, false); break;
-    case 4: pred_angular<BD>(a.src, a.stride, top, left, a.w, a.h, true, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
-    case 5: pred_angular<BD>(a.src, a.stride, top, left, a.w, a.h, false, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
-    default: pred_mip<BD>(a.src, a.stride, top, left, a.w, a.h, a.mip_mode, a.mip_transposed, scratch); break;
+    case 0: pred_planar<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h); break;
+    case 1: pred_dc<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, scratch); break;
+    case 2: pred_vh<BD, 256>(threadIdx.x, a.src, a.stride, top, a.w, a.h, true); break;
+    case 3: pred_vh<BD, 256>(threadIdx.x, a.src, a.stride, left, a.w, a.h, false); break;
+    case 4: pred_angular<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, true, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    case 5: pred_angular<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, false, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    default: pred_mip<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, a.mip_mode, a.mip_transposed, scratch); break;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ flattened intra_pred
 
 // vvc_intra_template.c:467-592 (edge preparation) + :595-683 (dispatch, PDPC); one workgroup per job.
-template <int BD>
-__global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs)
+// NT = 64: one wave per block (w*h <= 256), four blocks per workgroup, wave-level synchronisation; NT = 256: one workgroup per block.
+template <int BD, int NT>
+__global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs, int n_jobs)
 {
-    __shared__ uint16_t arr[4][kEdgeLen];
-    __shared__ int scratch[16];
-    const vvc355_intra_job j = jobs[blockIdx.x];
+    constexpr int TBS = 256 / NT;
+    __shared__ uint16_t arr_all[TBS][4][kEdgeLen];
+    __shared__ int scratch_all[TBS][16];
+    const int sub = threadIdx.x / NT;
+    const int ji = blockIdx.x * TBS + sub;
+    if (ji >= n_jobs)
+        return;
+    uint16_t (*arr)[kEdgeLen] = arr_all[sub];
+    int *scratch = scratch_all[sub];
+    const vvc355_intra_job j = jobs[ji];
     const ptrdiff_t stride = j.stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
-    const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x;
+    const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x % NT;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
     uint8_t *src = (uint8_t *)j.plane + ((ptrdiff_t)j.y * stride + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
     const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
@@ -281,9 +296,9 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
     }
     const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
 #define GETP(x, y) ld_px<BD>(src, (ptrdiff_t)(x) + stride * (ptrdiff_t)(y))
-    for (int i = tid; i < la; i += blockDim.x) left[i] = (uint16_t)GETP(ref_line, i);
-    for (int i = tid; i < ta; i += blockDim.x) top[i] = (uint16_t)GETP(i, ref_line);
-    __syncthreads();
+    for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
+    for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)GETP(i, ref_line);
+    group_sync<NT>();
     if (tid == 0) {
         for (int i = -1; i >= ref_line; i--) {
             if (j.cand_up_left) { left[i] = (uint16_t)GETP(ref_line, i); top[i] = (uint16_t)GETP(i, ref_line); }
@@ -292,21 +307,21 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
             else left[i] = top[i] = 1 << (BD - 1);
         }
     }
-    __syncthreads();
+    group_sync<NT>();
     {
         const uint16_t tfill = top[ta - 1], lfill = left[la - 1];
-        for (int i = ta + tid; i < utop; i += blockDim.x) top[i] = tfill;
-        for (int i = la + tid; i < uleft; i += blockDim.x) left[i] = lfill;
+        for (int i = ta + tid; i < utop; i += NT) top[i] = tfill;
+        for (int i = la + tid; i < uleft; i += NT) left[i] = lfill;
     }
-    __syncthreads();
+    group_sync<NT>();
     if (rff && smooth) {                                  // ref_filter (:450)
         const int keep_last = left_size == uleft;
         if (tid == 0)
             fleft[-1] = ftop[-1] = (uint16_t)((left[0] + 2 * left[-1] + top[0] + 2) >> 2);
-        for (int i = tid; i < uleft - keep_last; i += blockDim.x) fleft[i] = (uint16_t)((left[i - 1] + 2 * left[i] + left[i + 1] + 2) >> 2);
-        for (int i = tid; i < utop - keep_last; i += blockDim.x) ftop[i] = (uint16_t)((top[i - 1] + 2 * top[i] + top[i + 1] + 2) >> 2);
+        for (int i = tid; i < uleft - keep_last; i += NT) fleft[i] = (uint16_t)((left[i - 1] + 2 * left[i] + left[i + 1] + 2) >> 2);
+        for (int i = tid; i < utop - keep_last; i += NT) ftop[i] = (uint16_t)((top[i - 1] + 2 * top[i] + top[i + 1] + 2) >> 2);
         if (keep_last && tid == 0) { ftop[utop - 1] = top[utop - 1]; fleft[uleft - 1] = left[uleft - 1]; }
-        __syncthreads();
+        group_sync<NT>();
         left = fleft; top = ftop;
     }
     int filter_flag = 0;
@@ -320,38 +335,38 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
             if (mode >= 34) {
                 if (angle < 0) {
                     uint16_t *p = top - (ref_idx + 1);
-                    for (int x = -h + tid; x < 0; x += blockDim.x)
+                    for (int x = -h + tid; x < 0; x += NT)
                         p[x] = left[-1 - ref_idx + min((x * inv + 256) >> 9, h)];
                 } else {
                     const uint16_t v = top[refw - 1];
-                    for (int i = refw + tid; i <= refw + max(1, w / h) * ref_idx + 1; i += blockDim.x) top[i] = v;
+                    for (int i = refw + tid; i <= refw + max(1, w / h) * ref_idx + 1; i += NT) top[i] = v;
                 }
             } else {
                 if (angle < 0) {
                     uint16_t *p = left - (ref_idx + 1);
-                    for (int x = -w + tid; x < 0; x += blockDim.x)
+                    for (int x = -w + tid; x < 0; x += NT)
                         p[x] = top[-1 - ref_idx + min((x * inv + 256) >> 9, w)];
                 } else {
                     const uint16_t v = left[refh - 1];
-                    for (int i = refh + tid; i <= refh + max(1, h / w) * ref_idx + 1; i += blockDim.x) left[i] = v;
+                    for (int i = refh + tid; i <= refh + max(1, h / w) * ref_idx + 1; i += NT) left[i] = v;
                 }
             }
-            __syncthreads();
+            group_sync<NT>();
         }
     }
 
     LRef T{ top }, L{ left };
-    if (is_mip)          pred_mip<BD>(src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch);
-    else if (mode == 0)  pred_planar<BD>(src, stride, T, L, w, h);
-    else if (mode == 1)  pred_dc<BD>(src, stride, T, L, w, h, scratch);
-    else if (mode == 50) pred_vh<BD>(src, stride, T, w, h, true);
-    else if (mode == 18) pred_vh<BD>(src, stride, L, w, h, false);
-    else                 pred_angular<BD>(src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc);
+    if (is_mip)          pred_mip<BD, NT>(tid, src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch);
+    else if (mode == 0)  pred_planar<BD, NT>(tid, src, stride, T, L, w, h);
+    else if (mode == 1)  pred_dc<BD, NT>(tid, src, stride, T, L, w, h, scratch);
+    else if (mode == 50) pred_vh<BD, NT>(tid, src, stride, T, w, h, true);
+    else if (mode == 18) pred_vh<BD, NT>(tid, src, stride, L, w, h, false);
+    else                 pred_angular<BD, NT>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc);
 
     if (need_pdpc && !is_mip && (mode == 0 || mode == 1 || mode == 50 || mode == 18)) {      // :654-682
-        __syncthreads();
+        group_sync<NT>();
         const int scale = (ilog2i(w) + ilog2i(h) - 2) >> 2;
-        for (int i = tid; i < w * h; i += blockDim.x) {
+        for (int i = tid; i < w * h; i += NT) {
             const int y = i / w, x = i - y * w;
             const int val = GETP(x, y);
             int l, t, wl, wt;
@@ -446,10 +461,13 @@ using namespace vvc355;
 
 extern "C" {
 
-void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs)
+void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs, int max_log2_area)
 {
     if (n_jobs <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((intra_pred_kernel<BD>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
+    VVC355_BD_DISPATCH(bd, {
+        if (max_log2_area <= 8) hipLaunchKernelGGL((intra_pred_kernel<BD, 64>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+        else                    hipLaunchKernelGGL((intra_pred_kernel<BD, 256>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    });
     HIP_CHECK(hipGetLastError());
 }
 
@@ -502,7 +520,9 @@ void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
     vvc355_intra_job dj = *job;
     dj.plane = (uint64_t)(s.dev - (ptrdiff_t)y0 * s.pitch - (ptrdiff_t)x0 * px);
     dj.stride = (int32_t)s.pitch;
-    vvc355_intra_pred_batch(call.stream(), bd, call.upload(&dj, 1), 1);
+    int lg = 0;
+    while ((1 << lg) < job->w * job->h) lg++;
+    vvc355_intra_pred_batch(call.stream(), bd, call.upload(&dj, 1), 1, lg);
 }
 
 } // extern "C"

@@ -283,7 +283,8 @@ typedef struct vvc355_intra_job {
 } vvc355_intra_job;
 
 /* jobs of one launch must not depend on each other's output (e.g. one anti-diagonal of the RECON wavefront) */
-void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs);
+/* max_log2_area = max over the batch of log2(w * h): <= 8 maps one wave per block, larger one workgroup per block */
+void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_dev, int n_jobs, int max_log2_area);
 /* synchronous form: job->plane is a HOST address */
 void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job);
 
