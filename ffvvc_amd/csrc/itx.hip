@@ -56,22 +56,21 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
     return (int)acc;
 }
 
-// CLS 0: one wave per block of <= 256 coefficients (four blocks per workgroup, wave-level synchronisation only);
-// CLS 1: one 256-lane workgroup per block of <= 1024; CLS 2: <= 4096 (64x64).  Small blocks dominate real streams, so the
-// small classes keep their LDS footprint (and therefore the number of resident blocks per CU) proportionate.
-template <int BD, int CLS>
+// NT lanes share one block of at most CAP coefficients (CAP / NT = 4 elements per lane, 16 for 64x64):
+//   NT 4 / CAP 16 (4x4), NT 16 / CAP 64 (8x8), NT 64 / CAP 256 (16x16): sub-wave groups, wave-level synchronisation only;
+//   NT 256 / CAP 1024 (32x32) and NT 256 / CAP 4096 (64x64): one workgroup per block.
+// Small blocks dominate real streams, so their LDS footprint and lane count stay proportionate to their size.
+template <int BD, int NT, int CAP>
 __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
 {
-    // CLS 3: sixteen lanes per block of <= 16 coefficients (4x4 and smaller), sixteen blocks per workgroup
-    constexpr int CAP = CLS == 3 ? 16 : CLS == 0 ? 256 : CLS == 1 ? 1024 : 4096;
-    constexpr int NT = CLS == 3 ? 16 : CLS == 0 ? 64 : 256;          // lanes that share one block
+    constexpr bool WAVE = NT <= 64;                  // the group lives inside one wave
     constexpr int TBS = 256 / NT;                    // blocks per workgroup
     __shared__ __attribute__((aligned(16))) int buf_all[TBS][CAP];
     __shared__ __attribute__((aligned(16))) int tmp_all[TBS][CAP];
     __shared__ int8_t cos_lds[256];
 #define ITX_SYNC()                                                                  \
     do {                                                                            \
-        if (CLS == 0 || CLS == 3) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
+        if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
         else __syncthreads();                                                       \
     } while (0)
     cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
     const int ji = blockIdx.x * TBS + sub;
     if (ji >= n_jobs)
-        return;                                      // whole waves (CLS 0) or the whole workgroup leave together
+        return;                                      // whole groups leave together
     int *buf = buf_all[sub], *tmp = tmp_all[sub];
     const vvc355_itx_job job = jobs[ji];
     const int w = 1 << job.log2_w, h = 1 << job.log2_h, n = w * h;
@@ -146,8 +145,14 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
             bool small = true;
             for (int i = tid; i < n; i += NT)
                 small &= (unsigned)(buf[i] + (1 << 23)) < (1u << 24);
-            const bool all_small = (CLS == 0 || CLS == 3) ? true : (bool)__syncthreads_and(small);
-            const bool fast1 = (CLS == 0 || CLS == 3) ? false : all_small;     // wave classes: keep the exact 32-bit multiply
+            bool fast1;
+            if (WAVE) {
+                // group vote inside the wave: the NT lanes of this block occupy an aligned bit field of the ballot
+                const unsigned long long gm = (NT == 64 ? ~0ull : ((1ull << (NT & 63)) - 1)) << ((threadIdx.x & 63) & ~(NT - 1));
+                fast1 = (__ballot(small) & gm) == gm;
+            } else {
+                fast1 = (bool)__syncthreads_and(small);
+            }
             const int gx = (cnt2 + 3) >> 2, lgh = job.log2_h;
             const int8_t *mv = job.trv == TX_DCT2 ? nullptr : dxt_matrix(job.trv, h);
             for (int g = tid; g < (gx << lgh); g += NT) {
@@ -345,10 +350,11 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
     if (n_jobs <= 0) return;
     hipStream_t st = (hipStream_t)stream;
     VVC355_BD_DISPATCH(bd, {
-        if (max_log2_area <= 4)       hipLaunchKernelGGL((itx_kernel<BD, 3>), dim3((n_jobs + 15) / 16), dim3(256), 0, st, jobs_dev, n_jobs);
-        else if (max_log2_area <= 8)  hipLaunchKernelGGL((itx_kernel<BD, 0>), dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs_dev, n_jobs);
-        else if (max_log2_area <= 10) hipLaunchKernelGGL((itx_kernel<BD, 1>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
-        else                          hipLaunchKernelGGL((itx_kernel<BD, 2>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
+        if (max_log2_area <= 4)       hipLaunchKernelGGL((itx_kernel<BD, 4, 16>), dim3((n_jobs + 63) / 64), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 6)  hipLaunchKernelGGL((itx_kernel<BD, 16, 64>), dim3((n_jobs + 15) / 16), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 8)  hipLaunchKernelGGL((itx_kernel<BD, 64, 256>), dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs_dev, n_jobs);
+        else if (max_log2_area <= 10) hipLaunchKernelGGL((itx_kernel<BD, 256, 1024>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
+        else                          hipLaunchKernelGGL((itx_kernel<BD, 256, 4096>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
     });
     HIP_CHECK(hipGetLastError());
 }
