@@ -282,7 +282,7 @@ def build_chain(lib, torch, fr):
     sao_all = np.concatenate(sj)
     d_sao = fr.upload(sao_all.view(np.uint8))
     n_sao = len(sao_all)
-    chain.append(Stage("sao", f"sao_kernel<{bd}>", lambda st: lib.vvc355_sao_batch(st, bd, ptr(d_sao), n_sao, CTB, CTB), frame_bytes * 2))
+    chain.append(Stage("sao", f"sao_vec_kernel<{bd}>", lambda st: lib.vvc355_sao_ctb_batch(st, bd, ptr(d_sao), n_sao, CTB), frame_bytes * 2))
 
     # ---------------------------------------------------------------- ALF luma: classify + coefficient gather + 7x7 diamond, fused
     sets = alf_filter_sets(rng, 8)

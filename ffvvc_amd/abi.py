@@ -99,6 +99,7 @@ BATCH_SIGNATURES = {
     "blend_batch":      ("v", "pipiii"),
     "bdof_batch":       ("v", "pipi"),
     "sao_batch":        ("v", "pipiii"),
+    "sao_ctb_batch":    ("v", "pipii"),
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipii"),

@@ -107,6 +107,96 @@ __global__ __launch_bounds__(256) void sao_kernel(const vvc355_sao_job *__restri
     }
 }
 
+// Vectorised form for the batched stage (types 1 and 3): a lane owns 8 consecutive samples of one row (one 16-byte load
+// / store per row at 10-bit), a workgroup 16 rows x 128 columns.  Only lanes that touch the rectangle's outer ring, where the
+// border / restore rules of sao_restore_px apply, take the per-sample path.
+template <int BD>
+__global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
+{
+    using px_t = typename Px<BD>::type;
+    const vvc355_sao_job job = jobs[blockIdx.y];
+    const int w = job.w, h = job.h, type = job.type;
+    const int y = blockIdx.x * 16 + (threadIdx.x >> 4), x0 = (threadIdx.x & 15) * 8;
+    if (y >= h || x0 >= w)
+        return;
+    const px_t *src = (const px_t *)job.src;
+    const ptrdiff_t ss = job.src_stride / (ptrdiff_t)sizeof(px_t);
+    px_t *drow = (px_t *)((uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride);
+    const px_t *srow = src + (ptrdiff_t)y * ss;
+    const int eo = job.eo & 3;
+    const int dxa = kSaoNb[eo][0], dya = kSaoNb[eo][1], dxb = kSaoNb[eo][2], dyb = kSaoNb[eo][3];
+    // the per-sample rules only matter where a border / restore flag of that side is set (or the vector is partial)
+    const bool f_l = job.borders[0] | job.vert_edge[0] | job.diag_edge[0] | job.diag_edge[3];
+    const bool f_r = job.borders[2] | job.vert_edge[1] | job.diag_edge[1] | job.diag_edge[2];
+    const bool f_t = job.borders[1] | job.horiz_edge[0] | job.diag_edge[0] | job.diag_edge[1];
+    const bool f_b = job.borders[3] | job.horiz_edge[1] | job.diag_edge[2] | job.diag_edge[3];
+    const bool ring = (x0 == 0 && f_l) || (x0 + 8 >= w && (f_r || x0 + 8 > w)) || (y == 0 && f_t) || (y == h - 1 && f_b);
+    if (type == 3 && ring) {
+        // per-sample path: picture borders, unfilterable slice / tile edges, partial vectors
+        for (int x = x0; x < min(x0 + 8, w); x++) {
+            const int s = srow[x];
+            int v;
+            if (!sao_restore_px<BD>(job, x, y, s, v)) {
+                const int k = 2 + sign_of(s - (int)srow[x + dxa + dya * ss]) + sign_of(s - (int)srow[x + dxb + dyb * ss]);
+                v = clip_px<BD>(s + job.offset_val[kSaoCat[k]]);
+            }
+            drow[x] = (px_t)v;
+        }
+        return;
+    }
+    // 10 samples of a row: the lane's 8 plus one on each side (only loaded when that neighbour row / column is used)
+    int c[8], out[8];
+    {
+        px_t t[8];
+        __builtin_memcpy(t, __builtin_assume_aligned(srow + x0, sizeof(px_t) * 8), sizeof(t));
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = t[j];
+    }
+    if (type == 1) {
+        int band[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) band[k] = (k + job.band_position) & 31;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = (c[j] >> (BD - 5)) & 31;
+            int off = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
+            out[j] = clip_px<BD>(c[j] + off);
+        }
+    } else {
+        int a[8], b[8];
+        const px_t *ra = srow + dya * ss + x0, *rb = srow + dyb * ss + x0;
+        px_t ta[8], tb[8];
+        __builtin_memcpy(ta, __builtin_assume_aligned(ra, sizeof(px_t) * 8), sizeof(ta));
+        __builtin_memcpy(tb, __builtin_assume_aligned(rb, sizeof(px_t) * 8), sizeof(tb));
+        // neighbour a is (dxa, dya) away: shift the aligned vector by one sample and pull the missing end sample in
+        const int ea = dxa ? (int)ra[dxa < 0 ? -1 : 8] : 0, eb = dxb ? (int)rb[dxb < 0 ? -1 : 8] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            a[j] = dxa == 0 ? (int)ta[j] : dxa < 0 ? (j == 0 ? ea : (int)ta[j - 1]) : (j == 7 ? ea : (int)ta[j + 1]);
+            b[j] = dxb == 0 ? (int)tb[j] : dxb < 0 ? (j == 0 ? eb : (int)tb[j - 1]) : (j == 7 ? eb : (int)tb[j + 1]);
+        }
+        int offs[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) offs[k] = job.offset_val[kSaoCat[k]];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = 2 + sign_of(c[j] - a[j]) + sign_of(c[j] - b[j]);
+            const int off = k == 0 ? offs[0] : k == 1 ? offs[1] : k == 2 ? offs[2] : k == 3 ? offs[3] : offs[4];
+            out[j] = clip_px<BD>(c[j] + off);
+        }
+    }
+    if (x0 + 8 <= w) {
+        px_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = (px_t)out[j];
+        __builtin_memcpy(__builtin_assume_aligned(drow + x0, sizeof(px_t) * 8), t, sizeof(t));
+    } else {
+        for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)out[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ deblock
 
 // view of one 4-line (or 2-line) segment: p[i] at pix - (i+1)*xs, q[i] at pix + i*xs, lines ys apart (in pixels)
@@ -354,6 +444,14 @@ static void launch_sao(int bd, const vvc355_sao_job *jobs, int n, int max_w, int
     HIP_CHECK(hipGetLastError());
 }
 
+// batched stage: every job is type 1 (band) or 3 (edge + restore) on 16-byte aligned planes, width <= 128
+static void launch_sao_vec(int bd, const vvc355_sao_job *jobs, int n, int max_h, hipStream_t st)
+{
+    if (n <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_vec_kernel<BD>), dim3((max_h + 15) / 16, n), dim3(256), 0, st, jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
 static void launch_deblock(int bd, const vvc355_deblock_job *jobs, int n, hipStream_t st)
 {
     if (n <= 0) return;
@@ -389,6 +487,11 @@ extern "C" {
 void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
     launch_sao(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
+}
+
+void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_h)
+{
+    launch_sao_vec(bd, jobs_dev, n_jobs, max_h, (hipStream_t)stream);
 }
 
 void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs)

@@ -202,6 +202,8 @@ typedef struct vvc355_deblock_job {
 } vvc355_deblock_job;
 
 void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h);
+/* fast form of the frame stage: every job type 1 or 3, w <= 128, dst/src addresses and strides multiples of 16 bytes */
+void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_h);
 /* all jobs of one launch must be independent (e.g. every vertical edge of a frame, then every horizontal edge) */
 void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs);
 /* blend_job: dst = luma rectangle (in place), src0 = LUT of 2^bd pixel-typed entries */
