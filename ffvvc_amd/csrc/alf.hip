@@ -59,7 +59,7 @@ __device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc35
     const int w = job.w, h = job.h;
     const int x_min = -min((int)job.ext_l, apron), x_max = w - 1 + min((int)job.ext_r, apron);
     const int y_min = -min((int)job.ext_t, apron), y_max = h - 1 + min((int)job.ext_b, apron);
-    const int nchunk = kTileW / 8;
+    const int nchunk = min(kTileW / 8, (w + 23) >> 3);      // columns -8 .. w+7 only
     const bool aligned = (((uintptr_t)src | (uintptr_t)job.src_stride) & (sizeof(px_t) * 8 - 1)) == 0;
 
     for (int i = threadIdx.x; i < (rows + 6) * nchunk; i += blockDim.x) {
@@ -305,10 +305,9 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
     uint8_t *dst = (uint8_t *)job.dst;
     const int vb_pos = job.vb_pos;
     // lane -> 4 consecutive samples of one row
-    for (int i = threadIdx.x; i < rows * 32; i += blockDim.x) {
-        const int yl = i >> 5, x = (i & 31) * 4;
-        if (x >= job.w)
-            continue;
+    const int lpr = job.w >> 2;
+    for (int i = threadIdx.x; i < rows * lpr; i += blockDim.x) {
+        const int yl = i / lpr, x = (i - yl * lpr) * 4;
         const int y = y_base + yl, dist = vb_dist(y, vb_pos), tr0 = yl + 3;
         int out[4];
 #pragma unroll
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
             for (int k = 0; k < 6; k++) {
                 const int dy = min((int)kChromaTap[k][0], dist), dx = kChromaTap[k][1];
                 const int a = tile[tr0 + dy][tc0 + dx], b = tile[tr0 - dy][tc0 - dx];
-                sum += f[k] * (clip3(a - cur, -c[k], c[k]) + clip3(b - cur, -c[k], c[k]));
+                sum = mad24(f[k], clamp_sym(a - cur, c[k]) + clamp_sym(b - cur, c[k]), sum);
             }
             sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
             out[j] = clip_px<BD>(sum + cur);
