@@ -70,11 +70,11 @@ __device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc35
         uint16_t v[8];
         if (aligned && c0 >= 0 && c0 + 8 <= w) {
             if (BD > 8) {
-                const uint4 q = *(const uint4 *)(row + c0);
+                const uint4 q = gld<uint4>(row + c0);
                 *(uint4 *)&tile[r][k * 8] = q;
                 continue;
             } else {
-                const uint2 q = *(const uint2 *)(row + c0);
+                const uint2 q = gld<uint2>(row + c0);
                 const uint32_t d[2] = { q.x, q.y };
 #pragma unroll
                 for (int j = 0; j < 8; j++)
@@ -83,7 +83,7 @@ __device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc35
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                v[j] = row[clip3(c0 + j, x_min, x_max)];
+                v[j] = gld<px_t>(row + clip3(c0 + j, x_min, x_max));
         }
         uint4 q;
         q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16); q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
@@ -179,9 +179,9 @@ __device__ __forceinline__ void filter_block_regs(const Win &win, const int (&f)
         }
         uint8_t *d = drow + (ptrdiff_t)i * dst_stride;
         if (BD > 8)
-            *(uint2 *)d = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+            gst<uint2>(d, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
         else
-            *(uint32_t *)d = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+            gst<uint32_t>(d, out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24));
     }
 }
 
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
         for (int e = threadIdx.x; e < 4 * 25 * 12; e += blockDim.x) {
             const int t = e / 300, r = e - t * 300, cls = r / 12, k = r - cls * 12;
             const int idx = kAlfPerm[t][k];
-            const int q = clip_idx[cls * 12 + idx];
+            const int q = gld<uint8_t>(clip_idx + cls * 12 + idx);
             const int cv = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
-            ftab[e] = (uint32_t)(uint16_t)coeff_set[c2f[cls] * 12 + idx] | ((uint32_t)cv << 16);
+            ftab[e] = (uint32_t)(uint16_t)gld<int16_t>(coeff_set + gld<uint8_t>(c2f + cls) * 12 + idx) | ((uint32_t)cv << 16);
         }
     }
     __syncthreads();
@@ -326,9 +326,9 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
         }
         uint8_t *d = dst + (ptrdiff_t)y * job.dst_stride;
         if (BD > 8)
-            *(uint2 *)(d + x * 2) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+            gst<uint2>(d + x * 2, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
         else
-            *(uint32_t *)(d + x) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+            gst<uint32_t>(d + x, out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24));
     }
 }
 

@@ -30,13 +30,40 @@ __device__ __forceinline__ int clip_intp2(int v, int p) { return clip3(v, -(1 <<
 __device__ __forceinline__ int sign_of(int v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ int ilog2(unsigned v) { return 31 - __clz(v | 1); }
 
+// Job descriptors carry device addresses as integers, so the compiler sees generic ("flat") pointers and would emit
+// flat_load / flat_store, which arbitrate through both the LDS and the vector-memory path.  Every HBM access goes through
+// these helpers instead: an explicit global address space gives global_load / global_store.
+#define VVC355_GLOBAL __attribute__((address_space(1)))
+template <int N> struct RawBits;
+template <> struct RawBits<1> { typedef uint8_t type; };
+template <> struct RawBits<2> { typedef uint16_t type; };
+template <> struct RawBits<4> { typedef uint32_t type; };
+template <> struct RawBits<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct RawBits<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <typename T> __device__ __forceinline__ T gld(const void *p)
+{
+    typedef typename RawBits<sizeof(T)>::type raw_t;
+    const raw_t r = *(const VVC355_GLOBAL raw_t *)p;
+    T v;
+    __builtin_memcpy(&v, &r, sizeof(T));
+    return v;
+}
+template <typename T> __device__ __forceinline__ void gst(void *p, T v)
+{
+    typedef typename RawBits<sizeof(T)>::type raw_t;
+    raw_t r;
+    __builtin_memcpy(&r, &v, sizeof(T));
+    *(VVC355_GLOBAL raw_t *)p = r;
+}
+
+// pixel load / store on HBM planes (never on LDS)
 template <int BD> __device__ __forceinline__ int ld_px(const uint8_t *p, ptrdiff_t i)
 {
-    return reinterpret_cast<const typename Px<BD>::type *>(p)[i];
+    return ((const VVC355_GLOBAL typename Px<BD>::type *)p)[i];
 }
 template <int BD> __device__ __forceinline__ void st_px(uint8_t *p, ptrdiff_t i, int v)
 {
-    reinterpret_cast<typename Px<BD>::type *>(p)[i] = (typename Px<BD>::type)v;
+    ((VVC355_GLOBAL typename Px<BD>::type *)p)[i] = (typename Px<BD>::type)v;
 }
 
 // dispatch a kernel template on the runtime bit depth

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     px_t pred[PER];
     if (dst && e0 < n) {
         if (row_io) {
-            const px_t *prow = (const px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
+            const VVC355_GLOBAL px_t *prow = (const VVC355_GLOBAL px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
 #pragma unroll
             for (int q = 0; q < PER; q++)
                 pred[q] = prow[q];                   // contiguous, aligned to PER samples: merged into wide loads
@@ -104,19 +104,19 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int o = e0 + q;
-                pred[q] = o < n ? ((const px_t *)(dst + (ptrdiff_t)(o >> job.log2_w) * job.dst_stride))[o & (w - 1)] : (px_t)0;
+                pred[q] = o < n ? (px_t)ld_px<BD>(dst + (ptrdiff_t)(o >> job.log2_w) * job.dst_stride, o & (w - 1)) : (px_t)0;
             }
         }
     }
     if (PER == 1) {
         if (e0 < n)
-            buf[e0] = coeffs[e0];
+            buf[e0] = gld<int>(coeffs + e0);
     } else {
 #pragma unroll
         for (int c4 = 0; c4 < PER / 4; c4++) {
             const int e = e0 + c4 * 4;
             if (e < n)                               // n is a multiple of 4 for every block of >= 4 coefficients
-                *(int4 *)&buf[e] = *(const int4 *)&coeffs[e];
+                *(int4 *)&buf[e] = gld<int4>(coeffs + e);
         }
     }
     ITX_SYNC();
@@ -245,17 +245,17 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
         }
         if (job.store_coeffs) {
             if (PER == 1) {
-                coeffs[e0] = r[0];
+                gst<int>(coeffs + e0, r[0]);
             } else {
 #pragma unroll
                 for (int c4 = 0; c4 < PER / 4; c4++)
                     if (e0 + c4 * 4 < n)
-                        *(int4 *)&coeffs[e0 + c4 * 4] = make_int4(r[c4 * 4], r[c4 * 4 + 1], r[c4 * 4 + 2], r[c4 * 4 + 3]);
+                        gst<int4>(coeffs + e0 + c4 * 4, make_int4(r[c4 * 4], r[c4 * 4 + 1], r[c4 * 4 + 2], r[c4 * 4 + 3]));
             }
         }
         if (dst) {
             if (row_io) {
-                px_t *prow = (px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
+                VVC355_GLOBAL px_t *prow = (VVC355_GLOBAL px_t *)(dst + (ptrdiff_t)(e0 >> job.log2_w) * job.dst_stride) + (e0 & (w - 1));
                 px_t outv[PER];
 #pragma unroll
                 for (int q = 0; q < PER; q++)

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
     int c[8], out[8];
     {
         px_t t[8];
-        __builtin_memcpy(t, __builtin_assume_aligned(srow + x0, sizeof(px_t) * 8), sizeof(t));
+        if (BD > 8) { const uint4 q = gld<uint4>(srow + x0); __builtin_memcpy(t, &q, sizeof(t)); }
+        else { const uint2 q = gld<uint2>(srow + x0); __builtin_memcpy(t, &q, sizeof(t)); }
 #pragma unroll
         for (int j = 0; j < 8; j++) c[j] = t[j];
     }
@@ -168,10 +169,10 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
         int a[8], b[8];
         const px_t *ra = srow + dya * ss + x0, *rb = srow + dyb * ss + x0;
         px_t ta[8], tb[8];
-        __builtin_memcpy(ta, __builtin_assume_aligned(ra, sizeof(px_t) * 8), sizeof(ta));
-        __builtin_memcpy(tb, __builtin_assume_aligned(rb, sizeof(px_t) * 8), sizeof(tb));
+        if (BD > 8) { const uint4 qa = gld<uint4>(ra), qb = gld<uint4>(rb); __builtin_memcpy(ta, &qa, sizeof(ta)); __builtin_memcpy(tb, &qb, sizeof(tb)); }
+        else { const uint2 qa = gld<uint2>(ra), qb = gld<uint2>(rb); __builtin_memcpy(ta, &qa, sizeof(ta)); __builtin_memcpy(tb, &qb, sizeof(tb)); }
         // neighbour a is (dxa, dya) away: shift the aligned vector by one sample and pull the missing end sample in
-        const int ea = dxa ? (int)ra[dxa < 0 ? -1 : 8] : 0, eb = dxb ? (int)rb[dxb < 0 ? -1 : 8] : 0;
+        const int ea = dxa ? (int)gld<px_t>(ra + (dxa < 0 ? -1 : 8)) : 0, eb = dxb ? (int)gld<px_t>(rb + (dxb < 0 ? -1 : 8)) : 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             a[j] = dxa == 0 ? (int)ta[j] : dxa < 0 ? (j == 0 ? ea : (int)ta[j - 1]) : (j == 7 ? ea : (int)ta[j + 1]);
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
         px_t t[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) t[j] = (px_t)out[j];
-        __builtin_memcpy(__builtin_assume_aligned(drow + x0, sizeof(px_t) * 8), t, sizeof(t));
+        if (BD > 8) { uint4 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint4>(drow + x0, q); }
+        else { uint2 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint2>(drow + x0, q); }
     } else {
         for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)out[j];
     }

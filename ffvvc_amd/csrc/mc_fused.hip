@@ -87,7 +87,7 @@ __device__ __forceinline__ void fetch_window(const uint8_t *src, int src_stride,
         const int r = (lane >> 5) + 2 * it;
         const bool ok = col_ok && r < r_hi;
         const px_t *pp = ok ? p : base;
-        const uint16_t s = (uint16_t)*pp;
+        const uint16_t s = (uint16_t)gld<px_t>(pp);
         v[it] = ok ? s : (uint16_t)0;
         p += step;
     }
