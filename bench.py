@@ -173,7 +173,7 @@ def build_chain(lib, torch, fr):
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     tj = []
-    itx_launches = []          # (first job, count, log2 area): one launch per block size
+    itx_launches = []          # (first job, count, log2 size): one launch per block shape
     coeff_off = 0
     for c, (w, h) in enumerate(fr.dims):
         if c == 0:
@@ -204,7 +204,7 @@ def build_chain(lib, torch, fr):
             j["nzw"] = 1 + (rng.random(len(x0)) * lim_h).astype(np.int64)
             j["nzh"] = 1 + (rng.random(len(x0)) * lim_v).astype(np.int64)
             j["range"], j["bd"], j["store_coeffs"] = 15, bd, 0
-            itx_launches.append((sum(len(t) for t in tj), len(j), 2 * lg))
+            itx_launches.append((sum(len(t) for t in tj), len(j), lg))
             tj.append(j)
     coeffs = torch.randint(-(1 << 12), 1 << 12, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32)
     fr.keep.append(coeffs)
@@ -216,10 +216,10 @@ def build_chain(lib, torch, fr):
     jsz = itx_all.dtype.itemsize
 
     def launch_itx(st):
-        for (first, count, lg2) in itx_launches:
-            lib.vvc355_itx_batch(st, bd, ptr(d_itx) + first * jsz, count, lg2)
+        for (first, count, lg) in itx_launches:
+            lib.vvc355_itx_shape_batch(st, bd, ptr(d_itx) + first * jsz, count, lg, lg)
 
-    chain.append(Stage("itx_add_residual", f"itx_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz)))
+    chain.append(Stage("itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz)))
 
     # ---------------------------------------------------------------- LMCS inverse luma mapping
     lut = fr.upload(np.sort(rng.integers(0, 1 << bd, size=1 << bd)).astype(np.uint8 if bd == 8 else np.uint16))

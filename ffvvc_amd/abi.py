@@ -103,6 +103,7 @@ BATCH_SIGNATURES = {
     "deblock_batch":    ("v", "pipi"),
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipii"),
+    "itx_shape_batch":  ("v", "pipiii"),
     "intra_pred_batch": ("v", "pipii"),
     "cclm_batch":       ("v", "pipi"),
     "pred_fused_batch": ("v", "pipi"),

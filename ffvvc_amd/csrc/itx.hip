@@ -56,31 +56,18 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
     return (int)acc;
 }
 
-// NT lanes share one block of at most CAP coefficients (CAP / NT = 4 elements per lane, 16 for 64x64):
-//   NT 4 / CAP 16 (4x4), NT 16 / CAP 64 (8x8), NT 64 / CAP 256 (16x16): sub-wave groups, wave-level synchronisation only;
-//   NT 256 / CAP 1024 (32x32) and NT 256 / CAP 4096 (64x64): one workgroup per block.
-// Small blocks dominate real streams, so their LDS footprint and lane count stay proportionate to their size.
-template <int BD, int NT, int CAP>
-__global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
-{
-    constexpr bool WAVE = NT <= 64;                  // the group lives inside one wave
-    constexpr int TBS = 256 / NT;                    // blocks per workgroup
-    __shared__ __attribute__((aligned(16))) int buf_all[TBS][CAP];
-    __shared__ __attribute__((aligned(16))) int tmp_all[TBS][CAP];
-    __shared__ int8_t cos_lds[256];
 #define ITX_SYNC()                                                                  \
     do {                                                                            \
         if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
         else __syncthreads();                                                       \
     } while (0)
-    cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
-    __syncthreads();
-    const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
-    const int ji = blockIdx.x * TBS + sub;
-    if (ji >= n_jobs)
-        return;                                      // whole groups leave together
-    int *buf = buf_all[sub], *tmp = tmp_all[sub];
-    const vvc355_itx_job job = jobs[ji];
+
+// One transform block of any shape with w * h <= CAP, worked on by the NT lanes `tid` = 0..NT-1 of a group (NT <= 64: the
+// group sits inside one wave and synchronises at wave level; NT = 256: the whole workgroup).  buf / tmp: CAP ints of LDS each.
+template <int BD, int NT, int CAP>
+__device__ __forceinline__ void itx_generic_block(const vvc355_itx_job &job, int *buf, int *tmp, const int8_t *cos_lds, int tid)
+{
+    constexpr bool WAVE = NT <= 64;                  // the group lives inside one wave
     const int w = 1 << job.log2_w, h = 1 << job.log2_h, n = w * h;
     const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
     int *coeffs = (int *)job.coeffs;
@@ -88,7 +75,7 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     // I/O mapping: lane `tid` owns the PER consecutive elements starting at tid * PER (row-major), so coefficients move as
     // 16-byte vectors and pixels as 8/16-byte row segments.  The prediction samples the residual is added to are requested
     // together with the coefficients, long before they are needed (one memory round trip on the critical path, not two).
-    constexpr int PER = CAP / NT;                    // 1, 4, 4, 16
+    constexpr int PER = CAP >= NT ? CAP / NT : 1;    // 1, 4, 4, 16
     using px_t = typename Px<BD>::type;
     uint8_t *dst = (uint8_t *)job.dst;
     const int e0 = tid * PER;
@@ -273,8 +260,264 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
             }
         }
     }
-#undef ITX_SYNC
 }
+
+// NT lanes share one block of at most CAP coefficients (CAP / NT = 4 elements per lane, 16 for 64x64):
+//   NT 4 / CAP 16 (4x4), NT 16 / CAP 64 (8x8), NT 64 / CAP 256 (16x16): sub-wave groups, wave-level synchronisation only;
+//   NT 256 / CAP 1024 (32x32) and NT 256 / CAP 4096 (64x64): one workgroup per block.
+template <int BD, int NT, int CAP>
+__global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
+{
+    constexpr int TBS = 256 / NT;                    // blocks per workgroup
+    __shared__ __attribute__((aligned(16))) int buf_all[TBS][CAP];
+    __shared__ __attribute__((aligned(16))) int tmp_all[TBS][CAP];
+    __shared__ int8_t cos_lds[256];
+    cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
+    __syncthreads();
+    const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int ji = blockIdx.x * TBS + sub;
+    if (ji >= n_jobs)
+        return;                                      // whole groups leave together
+    const vvc355_itx_job job = jobs[ji];
+    if (job.log2_w + job.log2_h > __builtin_ctz(CAP))
+        return;                                      // larger than this launch's size class: contract violation, skipped
+    itx_generic_block<BD, NT, CAP>(job, buf_all[sub], tmp_all[sub], cos_lds, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ shape-specialised path
+//
+// All jobs of a launch share one shape W x H (both 4..64).  With log2_transform_range <= 15 the coefficients the reference
+// reads and its clipped first-stage results are 16-bit, so both passes are packed 16-bit dot products (v_dot2_i32_i16, two
+// multiply-adds per lane per instruction; the true sums stay far below 2^31, so the reference's wrapping int32 sums are
+// reproduced exactly).  A block is cut into 4x4 tiles, one lane per tile in each pass; per 8 inputs a lane reads 4 matrix
+// rows and 4 data rows as 16-byte LDS vectors and issues 64 dot products.  LDS images (int16, input index contiguous):
+//   cT [x][k]  the coefficients the column pass reads, transposed; rows / columns the nz gating excludes are zero
+//   tmp[y][k]  the clipped column-pass output, only the columns the row pass reads
+//   tab[type][out][k]  the transform matrices of this shape (generated: itx16_<N> in tables.inc)
+// Only the coefficients inside the nz window are fetched from HBM.  A workgroup in which any block is not eligible
+// (other shape, range > 15, a coefficient beyond 16 bits) redoes all of its blocks with the generic code above.
+
+typedef short itx_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(itx_v2s, a), __builtin_bit_cast(itx_v2s, b), acc, false);
+}
+__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+template <int N> struct TxDim {
+    static constexpr int KV = N < 32 ? N : 32;               // inputs an N-point inverse transform can read
+    static constexpr int P = KV + (KV >= 16 ? 8 : 0);        // LDS row pitch (int16): 16-byte aligned rows, staggered banks
+    static constexpr int KS = KV < 8 ? 4 : 8;                // inputs per LDS vector
+    static constexpr int NTYPE = N <= 32 ? 3 : 1;            // DST-7 / DCT-8 exist up to 32 points
+    __device__ static __forceinline__ const int16_t *table()
+    {
+        return N == 4 ? d_tab_itx16_4 : N == 8 ? d_tab_itx16_8 : N == 16 ? d_tab_itx16_16 : N == 32 ? d_tab_itx16_32 : d_tab_itx16_64;
+    }
+    // global -> LDS, re-pitched
+    __device__ static __forceinline__ void stage(int16_t *lds)
+    {
+        const int16_t *src = table();
+        constexpr int ND = NTYPE * N * KV / 2;
+        for (int i = threadIdx.x; i < ND; i += 256) {
+            const int row = i / (KV / 2), c2 = i % (KV / 2);
+            *(uint32_t *)&lds[row * P + 2 * c2] = gld<uint32_t>(src + 2 * i);
+        }
+    }
+};
+
+template <int KS> __device__ __forceinline__ void lds_row(const int16_t *p, uint32_t (&d)[KS / 2])
+{
+    if constexpr (KS == 8) {
+        const uint4 v = *(const uint4 *)p;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+        const uint2 v = *(const uint2 *)p;
+        d[0] = v.x; d[1] = v.y;
+    }
+}
+
+template <int BD, int LW, int LH>
+__global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__restrict__ jobs, int n_jobs)
+{
+    using px_t = typename Px<BD>::type;
+    constexpr int W = 1 << LW, H = 1 << LH, CAP = W * H;
+    constexpr int NT = CAP / 16, TBS = 256 / NT;             // lanes per block (one per 4x4 tile), blocks per workgroup
+    using DV = TxDim<H>;                                     // vertical transform: k runs over rows
+    using DH = TxDim<W>;                                     // horizontal transform: k runs over columns
+    constexpr int KVV = DV::KV, PV = DV::P, KSV = DV::KS;
+    constexpr int KVH = DH::KV, PH = DH::P, KSH = DH::KS;
+    constexpr bool WAVE = NT <= 64;
+    constexpr int CT_SZ = KVH * PV, TMP_SZ = H * PH;
+    constexpr int FAST_BYTES = TBS * (CT_SZ + TMP_SZ) * 2, GEN_BYTES = CAP * 8;
+    __shared__ __attribute__((aligned(16))) char lds_raw[FAST_BYTES > GEN_BYTES ? FAST_BYTES : GEN_BYTES];
+    __shared__ __attribute__((aligned(16))) int16_t tab_v[DV::NTYPE * H * PV];
+    __shared__ __attribute__((aligned(16))) int16_t tab_h_own[W == H ? 8 : DH::NTYPE * W * PH];
+    __shared__ int8_t cos_lds[256];
+    const int16_t *tab_h = W == H ? tab_v : tab_h_own;
+
+    DV::stage(tab_v);
+    if (W != H)
+        DH::stage(tab_h_own);
+    cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
+
+    const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int ji = blockIdx.x * TBS + sub;
+    const bool valid = ji < n_jobs;
+    const vvc355_itx_job job = jobs[valid ? ji : n_jobs - 1];
+    const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
+    const int trh = job.trh, trv = job.trv;
+    const int sh_final = 5 + range - bd;
+    bool ok = job.log2_w == LW && job.log2_h == LH && range <= 15 && sh_final >= 1 && trh < DH::NTYPE && trv < DV::NTYPE;
+    const bool dc_only = W == H && trh == TX_DCT2 && trv == TX_DCT2 && nzw == 1 && nzh == 1;
+    const int cntv = dc_only ? 1 : inputs_used(trv, H, nzh);                // rows the column pass reads
+    const int cnt2 = inputs_used(trh, W, nzw);                              // columns the row pass reads
+    ok &= cntv <= KVV && cnt2 <= KVH;
+    const int cnt2r = (cnt2 + KSH - 1) & ~(KSH - 1);
+
+    // this lane's tile for I/O and for the row pass
+    const int y0 = (tid / (W / 4)) * 4, x0 = (tid % (W / 4)) * 4;
+    int *coeffs = (int *)job.coeffs;
+    uint8_t *dst = (uint8_t *)job.dst;
+    const bool act = valid && ok;
+
+    // prediction samples first: they are needed last
+    uint2 praw[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        praw[r] = make_uint2(0, 0);
+        if (act && dst) {
+            const uint8_t *p = dst + (ptrdiff_t)(y0 + r) * job.dst_stride + x0 * (int)sizeof(px_t);
+            if (BD > 8) praw[r] = gld<uint2>(p);
+            else praw[r].x = gld<uint32_t>(p);
+        }
+    }
+    int c[4][4];
+    const bool need = act && y0 < cntv && x0 < nzw && x0 < KVH;
+    unsigned mag = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int4 v = make_int4(0, 0, 0, 0);
+        if (need && y0 + r < cntv)
+            v = gld<int4>(coeffs + (y0 + r) * W + x0);
+        c[r][0] = x0 + 0 < nzw ? v.x : 0; c[r][1] = x0 + 1 < nzw ? v.y : 0;
+        c[r][2] = x0 + 2 < nzw ? v.z : 0; c[r][3] = x0 + 3 < nzw ? v.w : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            mag |= (unsigned)(c[r][q] ^ (c[r][q] >> 31));
+    }
+    ok &= (mag >> 15) == 0;
+    if (!__syncthreads_and(!valid || ok)) {
+        // some block of this workgroup needs the generic arithmetic: redo them all, one after the other, 256 lanes each
+        int *gbuf = (int *)lds_raw, *gtmp = gbuf + CAP;
+        for (int b = 0; b < TBS; b++) {
+            const int jb = blockIdx.x * TBS + b;
+            if (jb >= n_jobs)
+                break;
+            const vvc355_itx_job jg = jobs[jb];
+            if (jg.log2_w + jg.log2_h <= LW + LH)
+                itx_generic_block<BD, 256, CAP>(jg, gbuf, gtmp, cos_lds, threadIdx.x);
+            __syncthreads();
+        }
+        return;
+    }
+    if (WAVE && !valid)
+        return;                                              // whole groups inside a wave; no workgroup barrier follows
+
+    int16_t *cT = (int16_t *)lds_raw + sub * (CT_SZ + TMP_SZ), *tmp = cT + CT_SZ;
+    if (y0 < KVV && x0 < KVH) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *(uint2 *)&cT[(x0 + q) * PV + y0] = make_uint2(pack_i16(c[0][q], c[1][q]), pack_i16(c[2][q], c[3][q]));
+    }
+    ITX_SYNC();
+
+    // ---- column pass: tile (rows ya.., columns xa..) of tmp, only the columns the row pass reads
+    {
+        constexpr int YT = H / 4;
+        const int xa = (tid / YT) * 4, ya = (tid % YT) * 4;
+        if (xa < cnt2r) {
+            int acc[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[r][q] = 0;
+            if (xa < nzw) {
+                const int16_t *mrow = tab_v + (trv * H + ya) * PV;
+                const int16_t *crow = cT + xa * PV;
+                for (int k = 0; k < cntv; k += KSV) {
+                    uint32_t m[4][KSV / 2], d[4][KSV / 2];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds_row<KSV>(mrow + r * PV + k, m[r]);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) lds_row<KSV>(crow + q * PV + k, d[q]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+#pragma unroll
+                            for (int e = 0; e < KSV / 2; e++) acc[r][q] = dot2_i16(m[r][e], d[q][e], acc[r][q]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = clip_intp2((acc[r][q] + 64) >> 7, range);
+                *(uint2 *)&tmp[(ya + r) * PH + xa] = make_uint2(pack_i16(v[0], v[1]), pack_i16(v[2], v[3]));
+            }
+        }
+    }
+    ITX_SYNC();
+
+    // ---- row pass on this lane's I/O tile
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[r][q] = 0;
+    {
+        const int16_t *mrow = tab_h + (trh * W + x0) * PH;
+        const int16_t *trow = tmp + y0 * PH;
+        for (int k = 0; k < cnt2; k += KSH) {
+            uint32_t m[4][KSH / 2], d[4][KSH / 2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) lds_row<KSH>(mrow + q * PH + k, m[q]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) lds_row<KSH>(trow + r * PH + k, d[r]);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int e = 0; e < KSH / 2; e++) acc[r][q] = dot2_i16(m[q][e], d[r][e], acc[r][q]);
+        }
+    }
+    if (!valid)
+        return;
+    const int rnd = 1 << (sh_final - 1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int res[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) res[q] = (acc[r][q] + rnd) >> sh_final;
+        if (job.store_coeffs)
+            gst<int4>(coeffs + (y0 + r) * W + x0, make_int4(res[0], res[1], res[2], res[3]));
+        if (dst) {
+            uint8_t *p = dst + (ptrdiff_t)(y0 + r) * job.dst_stride + x0 * (int)sizeof(px_t);
+            if (BD > 8) {
+                const int o0 = clip_px<BD>((int)(praw[r].x & 0xffff) + res[0]), o1 = clip_px<BD>((int)(praw[r].x >> 16) + res[1]);
+                const int o2 = clip_px<BD>((int)(praw[r].y & 0xffff) + res[2]), o3 = clip_px<BD>((int)(praw[r].y >> 16) + res[3]);
+                gst<uint2>(p, make_uint2((uint32_t)o0 | ((uint32_t)o1 << 16), (uint32_t)o2 | ((uint32_t)o3 << 16)));
+            } else {
+                const uint32_t pr = praw[r].x;
+                const int o0 = clip_px<BD>((int)(pr & 0xff) + res[0]), o1 = clip_px<BD>((int)((pr >> 8) & 0xff) + res[1]);
+                const int o2 = clip_px<BD>((int)((pr >> 16) & 0xff) + res[2]), o3 = clip_px<BD>((int)(pr >> 24) + res[3]);
+                gst<uint32_t>(p, (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16) | ((uint32_t)o3 << 24));
+            }
+        }
+    }
+}
+#undef ITX_SYNC
 
 // add_residual / add_residual_joint / pred_residual_joint (vvcdsp_template.c:32,48,65); job.src0 = int residuals,
 // mode 0 add, 1 joint add (w0 = c_sign, denom = shift), 2 joint in place on the int buffer (dst unused)
@@ -338,6 +581,33 @@ static bool itx_entry_exists(int trh, int trv, int lw, int lh)
     return true;
 }
 
+template <int BD, int LW>
+static void launch_itx_shape(hipStream_t st, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_h)
+{
+#define VVC355_ITX_SHAPE(LH)                                                                                          \
+    case LH: {                                                                                                        \
+        constexpr int TBS = 256 / ((1 << (LW + LH)) / 16);                                                            \
+        hipLaunchKernelGGL((itx_shape_kernel<BD, LW, LH>), dim3((n_jobs + TBS - 1) / TBS), dim3(256), 0, st, jobs_dev, n_jobs); \
+    } break;
+    switch (log2_h) {
+    VVC355_ITX_SHAPE(2) VVC355_ITX_SHAPE(3) VVC355_ITX_SHAPE(4) VVC355_ITX_SHAPE(5) VVC355_ITX_SHAPE(6)
+    }
+#undef VVC355_ITX_SHAPE
+}
+
+
+template <int BD>
+static void launch_itx_shape_any(hipStream_t st, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_w, int log2_h)
+{
+    switch (log2_w) {
+    case 2: launch_itx_shape<BD, 2>(st, jobs_dev, n_jobs, log2_h); break;
+    case 3: launch_itx_shape<BD, 3>(st, jobs_dev, n_jobs, log2_h); break;
+    case 4: launch_itx_shape<BD, 4>(st, jobs_dev, n_jobs, log2_h); break;
+    case 5: launch_itx_shape<BD, 5>(st, jobs_dev, n_jobs, log2_h); break;
+    case 6: launch_itx_shape<BD, 6>(st, jobs_dev, n_jobs, log2_h); break;
+    }
+}
+
 } // namespace vvc355
 
 using namespace vvc355;
@@ -359,6 +629,18 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
     HIP_CHECK(hipGetLastError());
 }
 
+void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_w, int log2_h)
+{
+    if (n_jobs <= 0) return;
+    if (log2_w < 2 || log2_w > 6 || log2_h < 2 || log2_h > 6) {
+        vvc355_itx_batch(stream, bd, jobs_dev, n_jobs, log2_w + log2_h);
+        return;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    VVC355_BD_DISPATCH(bd, launch_itx_shape_any<BD>(st, jobs_dev, n_jobs, log2_w, log2_h));
+    HIP_CHECK(hipGetLastError());
+}
+
 int vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
                intptr_t log2_transform_range, intptr_t bit_depth)
 {
@@ -371,8 +653,11 @@ int vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw
     job.trh = (uint8_t)trh; job.trv = (uint8_t)trv; job.log2_w = (uint8_t)log2_w; job.log2_h = (uint8_t)log2_h;
     job.nzw = (uint8_t)nzw; job.nzh = (uint8_t)nzh; job.range = (uint8_t)log2_transform_range; job.bd = (uint8_t)bit_depth;
     job.store_coeffs = 1;
-    vvc355_itx_batch(call.stream(), (int)bit_depth == 8 || (int)bit_depth == 10 || (int)bit_depth == 12 ? (int)bit_depth : 10,
-                     call.upload(&job, 1), 1, log2_w + log2_h);
+    const int kbd = (int)bit_depth == 8 || (int)bit_depth == 10 || (int)bit_depth == 12 ? (int)bit_depth : 10;
+    if (log2_w >= 2 && log2_h >= 2)
+        vvc355_itx_shape_batch(call.stream(), kbd, call.upload(&job, 1), 1, log2_w, log2_h);
+    else
+        vvc355_itx_batch(call.stream(), kbd, call.upload(&job, 1), 1, log2_w + log2_h);
     return 0;
 }
 

@@ -246,6 +246,11 @@ typedef struct vvc355_itx_job {
 
 /* max_log2_area = max over the batch of log2_w + log2_h; it selects the lanes-per-block mapping (<= 6: a wave per block) */
 void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int max_log2_area);
+/* Same work for a batch in which every job has the shape 2^log2_w x 2^log2_h (both 2..6): the packed 16-bit fast path
+ * (itx.hip, "shape-specialised path").  Jobs of a smaller area, log2_transform_range > 15 or coefficients beyond 16 bits
+ * are still computed exactly (generic arithmetic, slower); jobs of a larger area are skipped.  The decoder's TU loop
+ * (vvc_intra.c:464-472 via itx_2d, vvcdsp.c:94) is what a caller bins by tb size to fill these launches. */
+void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_w, int log2_h);
 
 /* VVCItxDSPContext.itx[trh][trv][log2 w][log2 h] — vvcdsp.h:118, vvcdsp.c:94-195.  Returns -1 (nothing done) for a
  * combination the reference table leaves NULL (vvcdsp_template.c:142-159), else 0. */

@@ -78,3 +78,81 @@ def test_residual_and_bdpcm(dev, orc, bd):
             outs.append((d0, d1, b, bp[0], bp[1]))
         for i, (x, y) in enumerate(zip(*outs)):
             assert np.array_equal(x, y), f"residual output {i} {w}x{h} bd={bd}"
+
+
+def _itx_frame_case(dev, orc, bd, rng, shapes, n_per_shape, wild):
+    """Tile a picture with transform blocks, run itx + residual add in one launch per shape, compare with the oracle's
+    itx followed by add_residual (what vvc_intra.c:464-472 chains per TU).  `wild` mixes in jobs the packed 16-bit path
+    must hand to the generic arithmetic (range 20 with 20-bit coefficients) inside otherwise eligible workgroups."""
+    from ffvvc_amd import abi, batch
+    isz = 1 if bd == 8 else 2
+    out = {}
+    for entry in ("shape", "area"):
+        for (lw, lh) in shapes:
+            w, h = 1 << lw, 1 << lh
+            cols = max(1, 256 // w)
+            rows = (n_per_shape + cols - 1) // cols
+            pic = rand_pixels(rng, (rows * h, cols * w), bd)
+            want = pic.copy()
+            pitched = batch.to_pitched(pic)
+            pitch = pitched.shape[1] * isz
+            d_pic = batch.DeviceBuffer.from_host(pitched)
+            coeffs = np.zeros((n_per_shape, h, w), np.int32)
+            arr = (abi.ItxJob * n_per_shape)()
+            for i in range(n_per_shape):
+                trh = int(rng.integers(0, 3)) if 4 <= w <= 32 else DCT2
+                trv = int(rng.integers(0, 3)) if 4 <= h <= 32 else DCT2
+                nzw = int(rng.integers(1, min(32 if trh == DCT2 else 16, w) + 1))
+                nzh = int(rng.integers(1, min(32 if trv == DCT2 else 16, h) + 1))
+                if rng.random() < 0.1:
+                    trh = trv = DCT2
+                    nzw = nzh = 1
+                rbits = 20 if (wild and rng.random() < 0.05) else 15
+                c = coeff_block(rng, w, h, nzw, nzh, rbits)
+                if rng.random() < 0.3:
+                    # garbage outside the nz window: never read by the reference for the rows / columns it gates off
+                    g = rng.integers(-(1 << 15), 1 << 15, size=(h, w))
+                    cntv = nzh if trv != DCT2 else min(h, 32, max(2, 1 << int(np.ceil(np.log2(nzh)))))
+                    if w == h and trh == DCT2 and trv == DCT2 and nzw == 1 and nzh == 1:
+                        cntv = 1
+                    keep = np.zeros((h, w), bool)
+                    keep[:cntv, :nzw] = True
+                    c = np.where(keep, c, g).astype(np.int32)
+                    # the reference does read rows nz..cntv-1 inside the window: keep those as they are in both runs
+                coeffs[i] = c
+                x0, y0 = (i % cols) * w, (i // cols) * h
+                ref = c.copy()
+                assert orc.orc_itx(trh, trv, lw, lh, P(ref), nzw, nzh, rbits, bd) == 0
+                blk = np.ascontiguousarray(want[y0:y0 + h, x0:x0 + w])
+                orc.orc_add_residual(bd, P(blk), P(ref), w, h, w * isz)
+                want[y0:y0 + h, x0:x0 + w] = blk
+                j = arr[i]
+                j.dst, j.dst_stride = d_pic.ptr + y0 * pitch + x0 * isz, pitch
+                j.trh, j.trv, j.log2_w, j.log2_h, j.nzw, j.nzh, j.range, j.bd = trh, trv, lw, lh, nzw, nzh, rbits, bd
+            d_c = batch.DeviceBuffer.from_host(coeffs)
+            for i in range(n_per_shape):
+                arr[i].coeffs = d_c.ptr + i * w * h * 4
+            d_jobs = batch.jobs_to_device(arr)
+            if entry == "shape":
+                dev.vvc355_itx_shape_batch(None, bd, d_jobs.ptr, n_per_shape, lw, lh)
+            else:
+                dev.vvc355_itx_batch(None, bd, d_jobs.ptr, n_per_shape, lw + lh)
+            dev.vvc355_stream_sync(None)
+            got = d_pic.to_host(pitched.dtype, pitched.shape)[:, :pic.shape[1]]
+            bad = np.argwhere(got != want)
+            assert len(bad) == 0, f"{entry} {w}x{h} bd={bd}: {len(bad)} samples differ, first at {bad[0].tolist()} (block {bad[0][0] // h * cols + bad[0][1] // w})"
+            out[(entry, lw, lh)] = n_per_shape
+    return out
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_itx_batches_with_residual_add(dev, orc, bd):
+    rng = np.random.default_rng(0x5EED0430 + bd)
+    shapes = [(lw, lh) for lw in range(2, 7) for lh in range(2, 7)]
+    done = _itx_frame_case(dev, orc, bd, rng, shapes, 150, wild=False)
+    assert len(done) == 50
+
+
+def test_itx_shape_batch_falls_back_exactly(dev, orc):
+    rng = np.random.default_rng(0x5EED0440)
+    _itx_frame_case(dev, orc, 10, rng, [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5), (6, 4), (5, 6)], 300, wild=True)
