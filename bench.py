@@ -172,8 +172,7 @@ def build_chain(lib, torch, fr):
                        intra_samples * isz))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
-    tj = []
-    itx_launches = []          # (first job, count, log2 size): one launch per block shape
+    by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape
     coeff_off = 0
     for c, (w, h) in enumerate(fr.dims):
         if c == 0:
@@ -204,8 +203,12 @@ def build_chain(lib, torch, fr):
             j["nzw"] = 1 + (rng.random(len(x0)) * lim_h).astype(np.int64)
             j["nzh"] = 1 + (rng.random(len(x0)) * lim_v).astype(np.int64)
             j["range"], j["bd"], j["store_coeffs"] = 15, bd, 0
-            itx_launches.append((sum(len(t) for t in tj), len(j), lg))
-            tj.append(j)
+            by_shape.setdefault(lg, []).append(j)
+    tj, itx_launches = [], []  # (first job, count, log2 size)
+    for lg in sorted(by_shape, reverse=True):
+        j = np.concatenate(by_shape[lg])
+        itx_launches.append((sum(len(t) for t in tj), len(j), lg))
+        tj.append(j)
     coeffs = torch.randint(-(1 << 12), 1 << 12, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32)
     fr.keep.append(coeffs)
     itx_all = np.concatenate(tj)

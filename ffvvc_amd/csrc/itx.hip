@@ -95,9 +95,11 @@ __device__ __forceinline__ void itx_generic_block(const vvc355_itx_job &job, int
             }
         }
     }
-    if (PER == 1) {
-        if (e0 < n)
-            buf[e0] = gld<int>(coeffs + e0);
+    if (PER < 4) {
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (e0 + q < n)
+                buf[e0 + q] = gld<int>(coeffs + e0 + q);
     } else {
 #pragma unroll
         for (int c4 = 0; c4 < PER / 4; c4++) {
@@ -231,8 +233,11 @@ __device__ __forceinline__ void itx_generic_block(const vvc355_itx_job &job, int
             r[q] = o < n ? (sh_final < 0 ? buf[o] : (buf[o] + (1 << (sh_final - 1))) >> sh_final) : 0;
         }
         if (job.store_coeffs) {
-            if (PER == 1) {
-                gst<int>(coeffs + e0, r[0]);
+            if (PER < 4) {
+#pragma unroll
+                for (int q = 0; q < PER; q++)
+                    if (e0 + q < n)
+                        gst<int>(coeffs + e0 + q, r[q]);
             } else {
 #pragma unroll
                 for (int c4 = 0; c4 < PER / 4; c4++)

@@ -12,16 +12,44 @@ namespace vvc355 {
 
 // ------------------------------------------------------------------------------------------------ LMCS
 
-// job.src0 = LUT (pixel-typed, 2^bd entries); in place on job.dst
+// job.src0 = LUT (pixel-typed, 2^bd entries); in place on job.dst.  The job's LUT is staged in LDS once per workgroup; a lane
+// maps 8 consecutive samples per step (one 16-byte load / store at 10-bit) when the rectangle's rows are vector-aligned.
 template <int BD>
 __global__ __launch_bounds__(256) void lmcs_kernel(const vvc355_blend_job *__restrict__ jobs)
 {
+    using px_t = typename Px<BD>::type;
+    constexpr int VB = 8 * (int)sizeof(px_t);                 // bytes per 8-sample vector
+    __shared__ __attribute__((aligned(16))) px_t lut_lds[1 << BD];
     const vvc355_blend_job job = jobs[blockIdx.y];
     const uint8_t *lut = (const uint8_t *)job.src0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
-        const int y = i / job.w, x = i - y * job.w;
-        uint8_t *row = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
-        st_px<BD>(row, x, ld_px<BD>(lut, ld_px<BD>(row, x)));
+    if ((job.src0 & 15) == 0) {
+        for (int i = threadIdx.x; i < (int)((sizeof(px_t) << BD) / 16); i += 256)
+            ((uint4 *)lut_lds)[i] = gld<uint4>(lut + i * 16);
+    } else {
+        for (int i = threadIdx.x; i < (1 << BD); i += 256)
+            lut_lds[i] = (px_t)ld_px<BD>(lut, i);
+    }
+    __syncthreads();
+    const int w = job.w, h = job.h;
+    uint8_t *dst = (uint8_t *)job.dst;
+    const bool vec = ((job.dst | (uint64_t)(uint32_t)job.dst_stride) & (VB - 1)) == 0;
+    const int wv = vec ? w >> 3 : 0;                          // whole vectors per row
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < wv * h; i += gridDim.x * 256) {
+        const int y = i / wv, xv = i - y * wv;
+        uint8_t *p = dst + (ptrdiff_t)y * job.dst_stride + xv * VB;
+        px_t t[8];
+        if (BD > 8) { const uint4 q = gld<uint4>(p); __builtin_memcpy(t, &q, sizeof(t)); }
+        else { const uint2 q = gld<uint2>(p); __builtin_memcpy(t, &q, sizeof(t)); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = lut_lds[t[k]];
+        if (BD > 8) { uint4 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint4>(p, q); }
+        else { uint2 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint2>(p, q); }
+    }
+    const int x_tail = wv * 8, wt = w - x_tail;               // columns left to the per-sample path
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < wt * h; i += gridDim.x * 256) {
+        const int y = i / wt, x = x_tail + i - y * wt;
+        uint8_t *row = dst + (ptrdiff_t)y * job.dst_stride;
+        st_px<BD>(row, x, lut_lds[ld_px<BD>(row, x)]);
     }
 }
 
@@ -107,6 +135,90 @@ __global__ __launch_bounds__(256) void sao_kernel(const vvc355_sao_job *__restri
     }
 }
 
+// ---- packed 16-bit helpers of the vectorised SAO: a register holds two samples
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t un(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_splat(int v) { return pk16{ (short)v, (short)v }; }
+// the compiler lowers min / max against small constants to compare + select per half: pin the packed instructions
+__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b)
+{
+    pk16 r;
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b)
+{
+    pk16 r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int BD> __device__ __forceinline__ void load8_pk(const typename Px<BD>::type *p, uint32_t (&d)[4])
+{
+    if (BD > 8) {
+        const uint4 q = gld<uint4>(p);
+        d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    } else {
+        const uint2 q = gld<uint2>(p);
+        d[0] = __builtin_amdgcn_perm(0, q.x, 0x0c010c00u); d[1] = __builtin_amdgcn_perm(0, q.x, 0x0c030c02u);
+        d[2] = __builtin_amdgcn_perm(0, q.y, 0x0c010c00u); d[3] = __builtin_amdgcn_perm(0, q.y, 0x0c030c02u);
+    }
+}
+template <int BD> __device__ __forceinline__ void store8_pk(typename Px<BD>::type *p, const uint32_t (&d)[4])
+{
+    if (BD > 8)
+        gst<uint4>(p, make_uint4(d[0], d[1], d[2], d[3]));
+    else
+        gst<uint2>(p, make_uint2(__builtin_amdgcn_perm(d[1], d[0], 0x06040200u), __builtin_amdgcn_perm(d[3], d[2], 0x06040200u)));
+}
+
+// the aligned vector t displaced by DX samples; e = the one sample beyond its end on that side
+template <int DX> __device__ __forceinline__ void shift8_pk(const uint32_t (&t)[4], uint32_t e, uint32_t (&o)[4])
+{
+    if (DX == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = t[i];
+    } else if (DX < 0) {
+        o[0] = (t[0] << 16) | e;
+#pragma unroll
+        for (int i = 1; i < 4; i++) o[i] = __builtin_amdgcn_alignbit(t[i], t[i - 1], 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) o[i] = __builtin_amdgcn_alignbit(t[i + 1], t[i], 16);
+        o[3] = (t[3] >> 16) | (e << 16);
+    }
+}
+
+struct SaoLut { uint32_t lo_a, lo_b, hi_a, hi_b; };      // bytes of the five offsets by category index 0..3 | 4
+
+// edge offset of 8 samples (h2656_sao_template.c:50-79): neighbours a / b one row up / down or in the same row (ra, rb point
+// at the samples above / below / beside x0), displaced by DXA / DXB columns
+template <int BD, int DXA, int DXB>
+__device__ __forceinline__ void sao_edge8(const typename Px<BD>::type *ra, const typename Px<BD>::type *rb, const uint32_t (&c)[4],
+                                          const SaoLut &lut, uint32_t (&out)[4])
+{
+    using px_t = typename Px<BD>::type;
+    uint32_t ta[4], tb[4], a[4], b[4];
+    load8_pk<BD>(ra, ta);
+    load8_pk<BD>(rb, tb);
+    const uint32_t ea = DXA ? (uint32_t)gld<px_t>(ra + (DXA < 0 ? -1 : 8)) : 0u;
+    const uint32_t eb = DXB ? (uint32_t)gld<px_t>(rb + (DXB < 0 ? -1 : 8)) : 0u;
+    shift8_pk<DXA>(ta, ea, a);
+    shift8_pk<DXB>(tb, eb, b);
+    const pk16 one = pk_splat(1), mone = pk_splat(-1), two = pk_splat(2), zero = pk_splat(0), top = pk_splat((1 << BD) - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const pk16 s1 = pk_max(pk_min(pk(c[i]) - pk(a[i]), one), mone);
+        const pk16 s2 = pk_max(pk_min(pk(c[i]) - pk(b[i]), one), mone);
+        const uint32_t idx = un(s1 + s2 + two);                              // 0..4 in the low byte of each half
+        const uint32_t off = __builtin_amdgcn_perm(lut.lo_b, lut.lo_a, idx | 0x0c000c00u)
+                           | __builtin_amdgcn_perm(lut.hi_b, lut.hi_a, (idx << 8) | 0x000c000cu);
+        const pk16 v = __builtin_elementwise_add_sat(pk(c[i]), pk(off));     // saturating: exact for any 16-bit offset
+        out[i] = un(pk_min(pk_max(v, zero), top));
+    }
+}
+
 // Vectorised form for the batched stage (types 1 and 3): a lane owns 8 consecutive samples of one row (one 16-byte load
 // / store per row at 10-bit), a workgroup 16 rows x 128 columns.  Only lanes that touch the rectangle's outer ring, where the
 // border / restore rules of sao_restore_px apply, take the per-sample path.
@@ -144,80 +256,134 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
         }
         return;
     }
-    // 10 samples of a row: the lane's 8 plus one on each side (only loaded when that neighbour row / column is used)
-    int c[8], out[8];
-    {
-        px_t t[8];
-        if (BD > 8) { const uint4 q = gld<uint4>(srow + x0); __builtin_memcpy(t, &q, sizeof(t)); }
-        else { const uint2 q = gld<uint2>(srow + x0); __builtin_memcpy(t, &q, sizeof(t)); }
-#pragma unroll
-        for (int j = 0; j < 8; j++) c[j] = t[j];
-    }
+    // the lane's 8 samples as four registers of two 16-bit samples each, whatever the storage type
+    uint32_t c[4], out[4];
+    load8_pk<BD>(srow + x0, c);
     if (type == 1) {
         int band[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) band[k] = (k + job.band_position) & 31;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int b = (c[j] >> (BD - 5)) & 31;
+            const int s = (c[j >> 1] >> ((j & 1) * 16)) & 0xffff;
+            const int b = (s >> (BD - 5)) & 31;
             int off = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
-            out[j] = clip_px<BD>(c[j] + off);
+            const uint32_t v = (uint32_t)clip_px<BD>(s + off);
+            out[j >> 1] = (j & 1) ? out[j >> 1] | (v << 16) : v;
         }
     } else {
-        int a[8], b[8];
-        const px_t *ra = srow + dya * ss + x0, *rb = srow + dyb * ss + x0;
-        px_t ta[8], tb[8];
-        if (BD > 8) { const uint4 qa = gld<uint4>(ra), qb = gld<uint4>(rb); __builtin_memcpy(ta, &qa, sizeof(ta)); __builtin_memcpy(tb, &qb, sizeof(tb)); }
-        else { const uint2 qa = gld<uint2>(ra), qb = gld<uint2>(rb); __builtin_memcpy(ta, &qa, sizeof(ta)); __builtin_memcpy(tb, &qb, sizeof(tb)); }
-        // neighbour a is (dxa, dya) away: shift the aligned vector by one sample and pull the missing end sample in
-        const int ea = dxa ? (int)gld<px_t>(ra + (dxa < 0 ? -1 : 8)) : 0, eb = dxb ? (int)gld<px_t>(rb + (dxb < 0 ? -1 : 8)) : 0;
+        // category -> offset as two byte look-ups (v_perm_b32): low bytes and high bytes of offset_val[kSaoCat[0..4]]
+        uint32_t lo_a = 0, hi_a = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            a[j] = dxa == 0 ? (int)ta[j] : dxa < 0 ? (j == 0 ? ea : (int)ta[j - 1]) : (j == 7 ? ea : (int)ta[j + 1]);
-            b[j] = dxb == 0 ? (int)tb[j] : dxb < 0 ? (j == 0 ? eb : (int)tb[j - 1]) : (j == 7 ? eb : (int)tb[j + 1]);
+        for (int k = 0; k < 4; k++) {
+            const uint32_t o = (uint16_t)job.offset_val[kSaoCat[k]];
+            lo_a |= (o & 0xff) << (8 * k);
+            hi_a |= (o >> 8) << (8 * k);
         }
-        int offs[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) offs[k] = job.offset_val[kSaoCat[k]];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = 2 + sign_of(c[j] - a[j]) + sign_of(c[j] - b[j]);
-            const int off = k == 0 ? offs[0] : k == 1 ? offs[1] : k == 2 ? offs[2] : k == 3 ? offs[3] : offs[4];
-            out[j] = clip_px<BD>(c[j] + off);
+        const uint32_t o4 = (uint16_t)job.offset_val[kSaoCat[4]];
+        const SaoLut lut = { lo_a, o4 & 0xff, hi_a, o4 >> 8 };
+        const px_t *ra = srow + dya * ss + x0, *rb = srow + dyb * ss + x0;
+        switch (eo) {
+        case 0:  sao_edge8<BD, -1, 1>(ra, rb, c, lut, out); break;
+        case 1:  sao_edge8<BD, 0, 0>(ra, rb, c, lut, out); break;
+        case 2:  sao_edge8<BD, -1, 1>(ra, rb, c, lut, out); break;
+        default: sao_edge8<BD, 1, -1>(ra, rb, c, lut, out); break;
         }
     }
     if (x0 + 8 <= w) {
-        px_t t[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) t[j] = (px_t)out[j];
-        if (BD > 8) { uint4 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint4>(drow + x0, q); }
-        else { uint2 q; __builtin_memcpy(&q, t, sizeof(t)); gst<uint2>(drow + x0, q); }
+        store8_pk<BD>(drow + x0, out);
     } else {
-        for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)out[j];
+        for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)((out[j >> 1] >> ((j & 1) * 16)) & 0xffff);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ deblock
 
-// view of one 4-line (or 2-line) segment: p[i] at pix - (i+1)*xs, q[i] at pix + i*xs, lines ys apart (in pixels)
+// One 4-line (or 2-line) segment held in registers: p[i] at pix - (i+1)*xs, q[i] at pix + i*xs, lines ys apart (in pixels).
+// Everything a decision can read is requested up front as 4-sample vectors (one memory round trip instead of one per decision
+// stage); only the samples a filter changes are written back, one by one, because the neighbouring edges' lanes own the rest.
 template <int BD> struct Dbk {
+    using px_t = typename Px<BD>::type;
     uint8_t *pix;
     ptrdiff_t xs, ys;
-    __device__ __forceinline__ int p(int l, int i) const { return ld_px<BD>(pix, l * ys - (i + 1) * xs); }
-    __device__ __forceinline__ int q(int l, int i) const { return ld_px<BD>(pix, l * ys + i * xs); }
+    int P[4][8], Q[4][8];
+    __device__ __forceinline__ int p(int l, int i) const { return P[l][i]; }
+    __device__ __forceinline__ int q(int l, int i) const { return Q[l][i]; }
+    // i in {3, 5, 7} / l in {1, 3}: selects between VALUES (the empty asm keeps the compiler from folding them back into one
+    // load from a selected address, which would force the whole struct into scratch memory)
+    static __device__ __forceinline__ int opaque(int v) { asm("" : "+v"(v)); return v; }
+    __device__ __forceinline__ int p_at(int l, int i) const { const int a = opaque(P[l][7]), b = opaque(P[l][5]), c = opaque(P[l][3]); return i == 7 ? a : i == 5 ? b : c; }
+    __device__ __forceinline__ int q_at(int l, int i) const { const int a = opaque(Q[l][7]), b = opaque(Q[l][5]), c = opaque(Q[l][3]); return i == 7 ? a : i == 5 ? b : c; }
+    __device__ __forceinline__ int pn(int l2, int i) const { const int a = opaque(P[1][i]), b = opaque(P[3][i]); return l2 == 1 ? a : b; }
+    __device__ __forceinline__ int qn(int l2, int i) const { const int a = opaque(Q[1][i]), b = opaque(Q[3][i]); return l2 == 1 ? a : b; }
     __device__ __forceinline__ void sp(int l, int i, int v) const { st_px<BD>(pix, l * ys - (i + 1) * xs, v); }
     __device__ __forceinline__ void sq(int l, int i, int v) const { st_px<BD>(pix, l * ys + i * xs, v); }
+
+    // n (2 or 4) consecutive samples at pixel offset o
+    __device__ __forceinline__ void vec(ptrdiff_t o, int n, int (&e)[4]) const
+    {
+        const px_t *a = (const px_t *)pix + o;
+        if (BD > 8) {
+            uint2 v = make_uint2(0, 0);
+            if (n == 4) v = gld<uint2>(a); else v.x = gld<uint32_t>(a);
+            e[0] = v.x & 0xffff; e[1] = v.x >> 16; e[2] = v.y & 0xffff; e[3] = v.y >> 16;
+        } else {
+            const uint32_t v = n == 4 ? gld<uint32_t>(a) : (uint32_t)gld<uint16_t>(a);
+            e[0] = v & 0xff; e[1] = (v >> 8) & 0xff; e[2] = (v >> 16) & 0xff; e[3] = v >> 24;
+        }
+    }
+    // samples [4 * half, 4 * half + 4) of both sides (which = 1: p, 2: q, 3: both) for `lines` lines
+    __device__ __forceinline__ void load(int lines, int half, int which)
+    {
+        const int b = 4 * half;
+        if (xs == 1) {
+            // p3..p0 | q0..q3 of a line are consecutive in memory
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                int e[4];
+                if (l < lines && (which & 1)) {
+                    vec(l * ys - b - 4, 4, e);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) P[l][b + 3 - k] = e[k];
+                }
+                if (l < lines && (which & 2)) {
+                    vec(l * ys + b, 4, e);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) Q[l][b + k] = e[k];
+                }
+            }
+        } else {
+            // the lines are consecutive in memory, p[i] / q[i] one row each
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int e[4];
+                if (which & 1) {
+                    vec(-(b + i + 1) * xs, lines, e);
+#pragma unroll
+                    for (int l = 0; l < 4; l++) P[l][b + i] = e[l];
+                }
+                if (which & 2) {
+                    vec((b + i) * xs, lines, e);
+#pragma unroll
+                    for (int l = 0; l < 4; l++) Q[l][b + i] = e[l];
+                }
+            }
+        }
+    }
 };
 __device__ __forceinline__ int d2(int a, int b, int c) { return abs(a - 2 * b + c); }
 
-__device__ static const uint8_t kW3[3] = { 53, 32, 11 }, kW5[5] = { 58, 45, 32, 19, 6 }, kW7[7] = { 59, 50, 41, 32, 23, 14, 5 };
-__device__ static const uint8_t kT3[3] = { 6, 4, 2 }, kT5[5] = { 6, 5, 4, 3, 2 }, kT7[7] = { 6, 5, 4, 3, 2, 1, 1 };
+// long-filter interpolation weights {53,32,11} {58,45,32,19,6} {59,50,41,32,23,14,5} and tc multipliers {6,4,2} {6,5,4,3,2} {6,5,4,3,2,1,1}
+// (vvc_filter_template.c:466-530) as arithmetic on the tap index
+__device__ __forceinline__ int long_w(int n, int i) { return n == 3 ? 53 - 21 * i : n == 5 ? 58 - 13 * i : 59 - 9 * i; }
+__device__ __forceinline__ int long_t(int n, int i) { return n == 3 ? 6 - 2 * i : n == 5 ? 6 - i : max(6 - i, 1); }
 
 template <int BD>
-__device__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int len_p, int len_q)
+__device__ __forceinline__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int len_p, int len_q)
 {
+#pragma unroll
     for (int l = 0; l < 4; l++) {
         int p[8], q[8], m;
 #pragma unroll
@@ -236,7 +402,6 @@ __device__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int
             m = (p[6] + p[5] + p[4] + p[3] + p[2] + p[1] + 2 * (q[2] + q[1] + q[0] + p[0]) + q[0] + q[1] + 8) >> 4;
         if (!no_p) {
             const int n = len_p == 3 ? 3 : len_p == 5 ? 5 : 7;
-            const uint8_t *wt = n == 3 ? kW3 : n == 5 ? kW5 : kW7, *tt = n == 3 ? kT3 : n == 5 ? kT5 : kT7;
             int ref = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) if (i == len_p || i == len_p - 1) ref += p[i];
@@ -244,13 +409,12 @@ __device__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int
 #pragma unroll
             for (int i = 0; i < 7; i++)
                 if (i < n) {
-                    const int lim = (tc * tt[i]) >> 1;
-                    d.sp(l, i, p[i] + clip3(((m * wt[i] + ref * (64 - wt[i]) + 32) >> 6) - p[i], -lim, lim));
+                    const int lim = (tc * long_t(n, i)) >> 1, wt = long_w(n, i);
+                    d.sp(l, i, p[i] + clip3(((m * wt + ref * (64 - wt) + 32) >> 6) - p[i], -lim, lim));
                 }
         }
         if (!no_q) {
             const int n = len_q == 3 ? 3 : len_q == 5 ? 5 : 7;
-            const uint8_t *wt = n == 3 ? kW3 : n == 5 ? kW5 : kW7, *tt = n == 3 ? kT3 : n == 5 ? kT5 : kT7;
             int ref = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) if (i == len_q || i == len_q - 1) ref += q[i];
@@ -258,15 +422,15 @@ __device__ void dbk_luma_large(const Dbk<BD> &d, int tc, int no_p, int no_q, int
 #pragma unroll
             for (int i = 0; i < 7; i++)
                 if (i < n) {
-                    const int lim = (tc * tt[i]) >> 1;
-                    d.sq(l, i, q[i] + clip3(((m * wt[i] + ref * (64 - wt[i]) + 32) >> 6) - q[i], -lim, lim));
+                    const int lim = (tc * long_t(n, i)) >> 1, wt = long_w(n, i);
+                    d.sq(l, i, q[i] + clip3(((m * wt + ref * (64 - wt) + 32) >> 6) - q[i], -lim, lim));
                 }
         }
     }
 }
 
 template <int BD>
-__device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q, int hor_ctu_edge)
+__device__ __forceinline__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q, int hor_ctu_edge)
 {
     const int tc = BD < 10 ? (tc_in + (1 << (9 - BD))) >> (10 - BD) : tc_in << (BD - 10);
     if (!tc)
@@ -292,10 +456,10 @@ __device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int n
             const int sq0l = abs(d.q(0, 0) - d.q(0, 3)) + (len_q == 7 ? abs(d.q(0, 4) - d.q(0, 5) - d.q(0, 6) + d.q(0, 7)) : 0);
             const int sp3l = abs(d.p(3, 3) - d.p(3, 0)) + (len_p == 7 ? abs(d.p(3, 7) - d.p(3, 6) - d.p(3, 5) + d.p(3, 4)) : 0);
             const int sq3l = abs(d.q(3, 0) - d.q(3, 3)) + (len_q == 7 ? abs(d.q(3, 4) - d.q(3, 5) - d.q(3, 6) + d.q(3, 7)) : 0);
-            const int sp0 = large_p ? (sp0l + abs(d.p(0, 3) - d.p(0, len_p)) + 1) >> 1 : sp0l;
-            const int sp3 = large_p ? (sp3l + abs(d.p(3, 3) - d.p(3, len_p)) + 1) >> 1 : sp3l;
-            const int sq0 = large_q ? (sq0l + abs(d.q(0, 3) - d.q(0, len_q)) + 1) >> 1 : sq0l;
-            const int sq3 = large_q ? (sq3l + abs(d.q(3, 3) - d.q(3, len_q)) + 1) >> 1 : sq3l;
+            const int sp0 = large_p ? (sp0l + abs(d.p(0, 3) - d.p_at(0, len_p)) + 1) >> 1 : sp0l;
+            const int sp3 = large_p ? (sp3l + abs(d.p(3, 3) - d.p_at(3, len_p)) + 1) >> 1 : sp3l;
+            const int sq0 = large_q ? (sq0l + abs(d.q(0, 3) - d.q_at(0, len_q)) + 1) >> 1 : sq0l;
+            const int sq3 = large_q ? (sq3l + abs(d.q(3, 3) - d.q_at(3, len_q)) + 1) >> 1 : sq3l;
             if (sp0 + sq0 < beta53 && abs(d.p(0, 0) - d.q(0, 0)) < tc25 &&
                 sp3 + sq3 < beta53 && abs(d.p(3, 0) - d.q(3, 0)) < tc25 &&
                 (d0l << 1) < beta_4 && (d3l << 1) < beta_4) {
@@ -313,6 +477,7 @@ __device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int n
         (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
         // strong filter, h2656_deblock_template.c:25
         const int tc2 = tc << 1, tc3 = tc * 3;
+#pragma unroll
         for (int l = 0; l < 4; l++) {
             const int p3 = d.p(l, 3), p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
             const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2), q3 = d.q(l, 3);
@@ -336,6 +501,7 @@ __device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int n
             if (dq0 + dq3 < side) nd_q = 2;
         }
         const int tc_2 = tc >> 1;
+#pragma unroll
         for (int l = 0; l < 4; l++) {
             const int p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
             const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2);
@@ -352,7 +518,7 @@ __device__ void dbk_luma_segment(const Dbk<BD> &d, int tc_in, int beta_in, int n
 }
 
 template <int BD>
-__device__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q)
+__device__ __forceinline__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int beta_in, int no_p, int no_q, int len_p, int len_q)
 {
     const int tc = BD < 10 ? (tc_in + (1 << (9 - BD))) >> (10 - BD) : tc_in << (BD - 10);
     if (!tc || !len_p || !len_q)
@@ -362,13 +528,13 @@ __device__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int b
     if (len_q == 3) {
         const bool one = len_p == 1;
         const int p0 = d.p(0, 0), p1 = d.p(0, 1), p2 = one ? p1 : d.p(0, 2), p3 = one ? p1 : d.p(0, 3);
-        const int p0n = d.p(l2, 0), p1n = d.p(l2, 1), p2n = one ? p1n : d.p(l2, 2);
+        const int p0n = d.pn(l2, 0), p1n = d.pn(l2, 1), p2n = one ? p1n : d.pn(l2, 2);
         const int q0 = d.q(0, 0), q1 = d.q(0, 1), q2 = d.q(0, 2), q3 = d.q(0, 3);
-        const int q0n = d.q(l2, 0), q1n = d.q(l2, 1), q2n = d.q(l2, 2);
+        const int q0n = d.qn(l2, 0), q1n = d.qn(l2, 1), q2n = d.qn(l2, 2);
         const int dd0 = d2(p2, p1, p0) + d2(q2, q1, q0), dd1 = d2(p2n, p1n, p0n) + d2(q2n, q1n, q0n);
         bool strong = false;
         if (dd0 + dd1 < beta) {
-            const int p3n = one ? p1n : d.p(l2, 3), q3n = d.q(l2, 3);
+            const int p3n = one ? p1n : d.pn(l2, 3), q3n = d.qn(l2, 3);
             const bool ok0 = (dd0 << 1) < beta_2 && abs(p3 - p0) + abs(q0 - q3) < beta_3 && abs(p0 - q0) < tc25;
             const bool ok1 = (dd1 << 1) < beta_2 && abs(p3n - p0n) + abs(q0n - q3n) < beta_3 && abs(p0n - q0n) < tc25;
             strong = ok0 && ok1;
@@ -377,7 +543,10 @@ __device__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int b
             len_p = len_q = 1;
     }
     const int kind = (len_p == 3 && len_q == 3) ? 2 : (len_q == 3) ? 1 : 0;
-    for (int l = 0; l < lines; l++) {
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        if (l >= lines)
+            continue;
         const int p3 = d.p(l, 3), p2 = d.p(l, 2), p1 = d.p(l, 1), p0 = d.p(l, 0);
         const int q0 = d.q(l, 0), q1 = d.q(l, 1), q2 = d.q(l, 2), q3 = d.q(l, 3);
         if (kind == 2) {
@@ -407,27 +576,53 @@ __device__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, int tc_in, int b
     }
 }
 
-// One lane per segment; a job is one reference slot call (8 samples along the edge = 2 luma segments, or 2 / 4 chroma ones).
+// Two lanes per job; a job is one reference slot call (8 samples along the edge): a lane takes one 4-line segment of a luma or
+// 4-line chroma job, or two of the four 2-line chroma segments.
 template <int BD>
 __global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *__restrict__ jobs, int n_jobs)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t >> 2, seg = t & 3;
+    const int j = t >> 1;
     if (j >= n_jobs)
         return;
-    const vvc355_deblock_job job = jobs[j];
-    const int lines = job.chroma ? (job.flag ? 2 : 4) : 4;
-    if (seg >= 8 / lines)
+    // fields indexed by the segment number are fetched individually (a register copy of the job would be indexed dynamically)
+    const vvc355_deblock_job *jp = jobs + j;
+    const uint32_t kind = gld<uint32_t>(&jp->dir);             // dir | chroma << 8 | flag << 16
+    const int dir = kind & 0xff, chroma = (kind >> 8) & 0xff, flag = (kind >> 16) & 0xff;
+    const int lines = chroma ? (flag ? 2 : 4) : 4;
+    const ptrdiff_t pxstride = gld<int32_t>(&jp->stride) / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    uint8_t *pix0 = (uint8_t *)gld<uint64_t>(&jp->pix);
+    const ptrdiff_t xs = dir == 0 ? pxstride : 1, ys = dir == 0 ? 1 : pxstride;
+    const int seg0 = t & 1;
+    if (!chroma) {
+        Dbk<BD> d;
+        d.xs = xs; d.ys = ys;
+        d.pix = pix0 + seg0 * 4 * ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
+        const int len_p = gld<uint8_t>(&jp->max_len_p[seg0]), len_q = gld<uint8_t>(&jp->max_len_q[seg0]);
+        const int far = (len_p > 3 && !flag ? 1 : 0) | (len_q > 3 ? 2 : 0);
+        d.load(4, 0, 3);
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int i = 4; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
+        if (far)
+            d.load(4, 1, far);
+        dbk_luma_segment<BD>(d, gld<int32_t>(&jp->tc[seg0]), gld<int32_t>(&jp->beta[seg0]), gld<uint8_t>(&jp->no_p[seg0]),
+                             gld<uint8_t>(&jp->no_q[seg0]), len_p, len_q, flag);
         return;
-    const ptrdiff_t pxstride = job.stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
-    Dbk<BD> d;
-    d.xs = job.dir == 0 ? pxstride : 1;
-    d.ys = job.dir == 0 ? 1 : pxstride;
-    d.pix = (uint8_t *)job.pix + seg * lines * d.ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
-    if (job.chroma)
-        dbk_chroma_segment<BD>(d, lines, job.tc[seg], job.beta[seg], job.no_p[seg], job.no_q[seg], job.max_len_p[seg], job.max_len_q[seg]);
-    else
-        dbk_luma_segment<BD>(d, job.tc[seg], job.beta[seg], job.no_p[seg], job.no_q[seg], job.max_len_p[seg], job.max_len_q[seg], job.flag);
+    }
+    for (int seg = seg0; seg < 8 / lines; seg += 2) {
+        Dbk<BD> d;
+        d.xs = xs; d.ys = ys;
+        d.pix = pix0 + seg * lines * ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
+        d.load(lines, 0, 3);
+        dbk_chroma_segment<BD>(d, lines, gld<int32_t>(&jp->tc[seg]), gld<int32_t>(&jp->beta[seg]), gld<uint8_t>(&jp->no_p[seg]),
+                               gld<uint8_t>(&jp->no_q[seg]), gld<uint8_t>(&jp->max_len_p[seg]), gld<uint8_t>(&jp->max_len_q[seg]));
+    }
 }
 
 template <int BD>
@@ -457,7 +652,7 @@ static void launch_sao_vec(int bd, const vvc355_sao_job *jobs, int n, int max_h,
 static void launch_deblock(int bd, const vvc355_deblock_job *jobs, int n, hipStream_t st)
 {
     if (n <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((deblock_kernel<BD>), dim3((n * 4 + 255) / 256), dim3(256), 0, st, jobs, n));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((deblock_kernel<BD>), dim3((n * 2 + 255) / 256), dim3(256), 0, st, jobs, n));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -504,7 +699,7 @@ void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_d
 void vvc355_lmcs_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
     if (n_jobs <= 0) return;
-    const int gx = max(1, min(16, (max_w * max_h + 1023) / 1024));
+    const int gx = max(1, min(64, (max_w * max_h + 8191) / 8192));      // 4 vectors of 8 samples per lane
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((lmcs_kernel<BD>), dim3(gx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev));
     HIP_CHECK(hipGetLastError());
 }

@@ -155,4 +155,4 @@ def test_itx_batches_with_residual_add(dev, orc, bd):
 
 def test_itx_shape_batch_falls_back_exactly(dev, orc):
     rng = np.random.default_rng(0x5EED0440)
-    _itx_frame_case(dev, orc, 10, rng, [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5), (6, 4), (5, 6)], 300, wild=True)
+    _itx_frame_case(dev, orc, 10, rng, [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5), (6, 4), (5, 6), (3, 6), (5, 4)], 300, wild=True)

@@ -35,6 +35,34 @@ def test_lmcs(dev, orc, bd):
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
+def test_lmcs_batch_rectangles(dev, orc, bd):
+    """One launch, one LUT per job, rectangles at aligned and unaligned positions of a pitched plane (the vector path
+    and the per-sample path of lmcs_kernel)."""
+    from ffvvc_amd import abi, batch
+    rng = np.random.default_rng(0x5EED0305 + bd)
+    pic = rand_pixels(rng, (200, 400), bd)
+    isz = pic.itemsize
+    want = pic.copy()
+    pitched = batch.to_pitched(pic)
+    pitch = pitched.shape[1] * isz
+    d_pic = batch.DeviceBuffer.from_host(pitched)
+    rects = [(0, 0, 128, 128), (128, 0, 128, 64), (256, 0, 100, 37), (131, 70, 61, 50), (0, 130, 7, 70), (16, 130, 40, 1), (64, 136, 129, 64)]
+    luts = [rand_pixels(rng, (1 << bd,), bd) for _ in rects]
+    d_luts = [batch.DeviceBuffer.from_host(lut) for lut in luts]
+    arr = (abi.BlendJob * len(rects))()
+    for i, (x, y, w, h) in enumerate(rects):
+        blk = np.ascontiguousarray(want[y:y + h, x:x + w])
+        orc.orc_lmcs_filter(bd, P(blk), w * isz, w, h, P(luts[i]))
+        want[y:y + h, x:x + w] = blk
+        arr[i].dst, arr[i].dst_stride, arr[i].src0, arr[i].w, arr[i].h = d_pic.ptr + y * pitch + x * isz, pitch, d_luts[i].ptr, w, h
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_lmcs_batch(None, bd, d_jobs.ptr, len(rects), 129, 128)
+    dev.vvc355_stream_sync(None)
+    got = d_pic.to_host(pitched.dtype, pitched.shape)[:, :pic.shape[1]]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_sao(dev, orc, bd):
     rng = np.random.default_rng(0x5EED0310 + bd)
     ss = (2 * 128 + 64) // (1 if bd == 8 else 2)          # implicit edge source stride in pixels
