@@ -57,6 +57,7 @@ SLOT_SIGNATURES = {
     # ---- inverse transform / residual (no leading bd where the reference slot is bit-depth independent)
     "itx":                  ("i", "iiiipzzqq"),
     "inv_lfnst_1d":         ("v", "ppiiiii"),
+    "dequant":              ("v", "piiiiiiiiiiipii"),
     "add_residual":         ("v", "ippiiq"),
     "add_residual_joint":   ("v", "ippiiqii"),
     "pred_residual_joint":  ("v", "piiii"),
@@ -104,9 +105,11 @@ BATCH_SIGNATURES = {
     "lmcs_batch":       ("v", "pipiii"),
     "itx_batch":        ("v", "pipii"),
     "itx_shape_batch":  ("v", "pipiii"),
+    "dequant_batch":    ("v", "ppi"),
     "intra_pred_batch": ("v", "pipii"),
     "cclm_batch":       ("v", "pipi"),
     "pred_fused_batch": ("v", "pipi"),
+    "bipred_batch":     ("v", "pipi"),
 }
 
 
@@ -204,6 +207,39 @@ class ItxJob(ctypes.Structure):
         ("trh", ctypes.c_uint8), ("trv", ctypes.c_uint8), ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8),
         ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8), ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8),
         ("store_coeffs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 3),
+    ]
+
+
+class BipredJob(ctypes.Structure):
+    """Mirror of vvc355_bipred_job (and of the oracle's orc_bipred_job)."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("ref0", ctypes.c_uint64), ("ref1", ctypes.c_uint64), ("rec", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("ref0_stride", ctypes.c_int32), ("ref1_stride", ctypes.c_int32),
+        ("mv", ctypes.c_int32 * 4),
+        ("x", ctypes.c_int16), ("y", ctypes.c_int16), ("w", ctypes.c_int16), ("h", ctypes.c_int16),
+        ("pic_w", ctypes.c_int16), ("pic_h", ctypes.c_int16),
+        ("denom", ctypes.c_int16), ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
+        ("chroma", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("dmvr", ctypes.c_uint8),
+        ("bdof", ctypes.c_uint8), ("hf_idx", ctypes.c_uint8), ("vf_idx", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
+        ("pad_", ctypes.c_uint8 * 6),
+    ]
+
+
+class BipredResult(ctypes.Structure):
+    """Mirror of vvc355_bipred_result."""
+    _fields_ = [("mv", ctypes.c_int32 * 4), ("bdof", ctypes.c_int32), ("min_sad", ctypes.c_int32),
+                ("searched", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class DequantJob(ctypes.Structure):
+    """Mirror of vvc355_dequant_job."""
+    _fields_ = [
+        ("coeffs", ctypes.c_uint64), ("scale_matrix", ctypes.c_uint64),
+        ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8), ("min_x", ctypes.c_uint8), ("min_y", ctypes.c_uint8),
+        ("max_x", ctypes.c_uint8), ("max_y", ctypes.c_uint8),
+        ("qp", ctypes.c_uint8), ("ts", ctypes.c_uint8), ("dep_quant", ctypes.c_uint8), ("bit_depth", ctypes.c_uint8),
+        ("range", ctypes.c_uint8), ("log2_matrix_size", ctypes.c_uint8),
+        ("dc", ctypes.c_int16), ("pad_", ctypes.c_uint8 * 2),
     ]
 
 

@@ -524,6 +524,43 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
 }
 #undef ITX_SYNC
 
+// Scaling process for transform coefficients (vvc_intra.c:277-417): one workgroup per transform block, lanes over the scan
+// rectangle.  levelScale / qp arithmetic per derive_qp (:277) and derive_scale (:311).
+__global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *__restrict__ jobs)
+{
+    const vvc355_dequant_job job = jobs[blockIdx.x];
+    const int lw = job.log2_w, lh = job.log2_h, log_sum = lw + lh;
+    const int rect = job.ts ? 0 : (log_sum & 1);
+    const int bd_shift = job.ts ? 10 : job.bit_depth + rect + (log_sum / 2) + 10 - job.range + job.dep_quant;
+    const int bd_offset = (1 << bd_shift) >> 1;
+    const int qp = job.qp + (job.dep_quant && !job.ts ? 1 : 0);
+    const int ls0[6] = { 40, 45, 51, 57, 64, 72 }, ls1[6] = { 57, 64, 72, 80, 90, 102 };
+    const int rem = qp % 6;
+    int lsv = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k == rem) lsv = rect ? ls1[k] : ls0[k];
+    const int scale = lsv << (qp / 6);
+    const int rw = job.max_x - job.min_x + 1, rh = job.max_y - job.min_y + 1;
+    int *coeffs = (int *)job.coeffs;
+    const uint8_t *sm = (const uint8_t *)job.scale_matrix;
+    const int lm = job.log2_matrix_size;
+    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+        const int y = job.min_y + i / rw, x = job.min_x + i % rw;
+        const int c = gld<int>(coeffs + (y << lw) + x);
+        if (!c)
+            continue;
+        int m = 16;
+        if (sm) {
+            // derive_scale_m :373-381: nearest-neighbour up-sampling of the recorded matrix, DC override at the origin
+            m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
+            if (job.dc >= 0 && i == 0 && job.min_x == 0 && job.min_y == 0)
+                m = job.dc;
+        }
+        const int v = (int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift;
+        gst<int>(coeffs + (y << lw) + x, clip_intp2(v, job.range));
+    }
+}
+
 // add_residual / add_residual_joint / pred_residual_joint (vvcdsp_template.c:32,48,65); job.src0 = int residuals,
 // mode 0 add, 1 joint add (w0 = c_sign, denom = shift), 2 joint in place on the int buffer (dst unused)
 template <int BD>
@@ -644,6 +681,28 @@ void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev
     hipStream_t st = (hipStream_t)stream;
     VVC355_BD_DISPATCH(bd, launch_itx_shape_any<BD>(st, jobs_dev, n_jobs, log2_w, log2_h));
     HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_dequant_batch(void *stream, const vvc355_dequant_job *jobs_dev, int n_jobs)
+{
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(dequant_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_dequant(int *coeffs, int log2_w, int log2_h, int min_x, int min_y, int max_x, int max_y, int qp, int ts,
+                    int dep_quant, int bit_depth, int log2_transform_range, const uint8_t *scale_matrix, int log2_matrix_size, int dc)
+{
+    SlotCall call;
+    vvc355_dequant_job job = {};
+    job.coeffs = (uint64_t)call.linear(coeffs, (sizeof(int) << (log2_w + log2_h)), true, true);
+    if (scale_matrix)
+        job.scale_matrix = (uint64_t)call.linear(scale_matrix, (size_t)1 << (2 * log2_matrix_size), true, false);
+    job.log2_w = (uint8_t)log2_w; job.log2_h = (uint8_t)log2_h;
+    job.min_x = (uint8_t)min_x; job.min_y = (uint8_t)min_y; job.max_x = (uint8_t)max_x; job.max_y = (uint8_t)max_y;
+    job.qp = (uint8_t)qp; job.ts = (uint8_t)ts; job.dep_quant = (uint8_t)dep_quant; job.bit_depth = (uint8_t)bit_depth;
+    job.range = (uint8_t)log2_transform_range; job.log2_matrix_size = (uint8_t)log2_matrix_size; job.dc = (int16_t)dc;
+    vvc355_dequant_batch(call.stream(), call.upload(&job, 1), 1);
 }
 
 int vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,

@@ -19,6 +19,10 @@
 
 namespace vvc355 {
 
+#define VVC355_TABLE(type, name, count) __device__ static const type d_tab_##name[count]
+#include "tables.inc"
+#undef VVC355_TABLE
+
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
@@ -245,6 +249,406 @@ __global__ __launch_bounds__(256) void pred_fused_kernel(const vvc355_pred_job *
     }
 }
 
+// ------------------------------------------------------------------------------------------------ regular bi-prediction
+//
+// One wave per sub-block of at most 16x16: what pred_regular_blk (vvc_inter.c:772-822) does around the slots, on device.
+// Every read of a reference plane goes through clamped coordinates (edge emulation, vvc_inter.c:33-110).
+
+struct ClampRect { int x0, y0, x1, y1; };               // inclusive, in samples of the component
+
+// NIT row pairs of a window whose index (0, 0) is plane sample (wx0, wy0): lane -> column lane & 31, rows (lane >> 5) + 2 it
+template <int BD, int NIT>
+__device__ __forceinline__ void fetch_clamped(const uint8_t *plane, int stride, const ClampRect &rc, int wx0, int wy0, int lane,
+                                              uint16_t (&v)[NIT])
+{
+    using px_t = typename Px<BD>::type;
+    const int xa = clip3(wx0 + (lane & 31), rc.x0, rc.x1);
+    const uint8_t *col = plane + (ptrdiff_t)xa * (int)sizeof(px_t);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int ya = clip3(wy0 + (lane >> 5) + 2 * it, rc.y0, rc.y1);
+        v[it] = (uint16_t)gld<px_t>(col + (ptrdiff_t)ya * stride);
+    }
+}
+
+template <int NIT>
+__device__ __forceinline__ void store_rows(uint16_t *win, int lane, const uint16_t (&v)[NIT])
+{
+    const int c = lane & 31;
+    if (c < kWinW) {
+        uint16_t *q = win + (lane >> 5) * kWinW + c;
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+            if ((lane >> 5) + 2 * it < kWinH)
+                q[it * 2 * kWinW] = v[it];
+    }
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+static constexpr int kBilP = 20;        // DMVR bilinear plane pitch: (16 + 4) columns
+static constexpr int kGs = 18;          // BDOF planes: block + one-sample ring
+
+struct BipredLds {
+    uint16_t win[2][kWinH * kWinW];
+    int16_t tmpT[16 * kTmpP];
+    int16_t smp[2][kGs * kGs];
+    union {
+        int16_t grad[4][kGs * kGs];      // gh0, gh1, gv0, gv1
+        int16_t bil[2][kBilP * kBilP];   // DMVR search planes (dead before the gradients are written)
+    };
+    int sad[28];
+};
+
+// vvc_inter.c:642-681
+__device__ __forceinline__ int parametric_mv_refine(int sad_minus, int sad_center, int sad_plus)
+{
+    int denom = ((sad_minus + sad_plus) - (sad_center << 1)) << 3;
+    if (!denom)
+        return 0;
+    if (sad_minus == sad_center)
+        return -8;
+    if (sad_plus == sad_center)
+        return 8;
+    int num = (sad_minus - sad_plus) * 16, quotient = 0;
+    const bool neg = num < 0;
+    if (neg)
+        num = -num;
+#pragma unroll
+    for (int counter = 0; counter < 3; counter++) {
+        quotient <<= 1;
+        if (num >= denom) {
+            num -= denom;
+            quotient++;
+        }
+        denom >>= 1;
+    }
+    return neg ? -quotient : quotient;
+}
+
+// dmvr_mv_refine (vvc_inter.c:685-748): refines mv in place, may clear bdof
+template <int BD>
+__device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, BipredLds &L, int lane, int (&mv)[4], int &bdof,
+                                            int &min_sad_out, int &searched)
+{
+    const int w = job->w, h = job->h, pw = w + 4, ph = h + 4;
+    const ClampRect pic = { 0, 0, job->pic_w - 1, job->pic_h - 1 };
+    {
+        // (pw + 1) x (ph + 1) integer samples around each reference block, two rows back (emulated_edge_bilinear :90-110)
+        uint16_t r0[11], r1[11];
+        fetch_clamped<BD, 11>((const uint8_t *)job->ref0, job->ref0_stride, pic, job->x + (mv[0] >> 4) - 2, job->y + (mv[1] >> 4) - 2, lane, r0);
+        fetch_clamped<BD, 11>((const uint8_t *)job->ref1, job->ref1_stride, pic, job->x + (mv[2] >> 4) - 2, job->y + (mv[3] >> 4) - 2, lane, r1);
+        store_rows<11>(L.win[0], lane, r0);
+        store_rows<11>(L.win[1], lane, r1);
+        wave_sync();
+    }
+    // inter.dmvr[!!my][!!mx] (vvc_inter_template.c:324-413): lane -> column lane & 31, rows (lane >> 5) + 2 it
+    const int sh1 = BD - 6, off1 = 1 << (sh1 - 1);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int mx = mv[2 * i] & 15, my = mv[2 * i + 1] & 15;
+        const uint16_t *win = L.win[i];
+        const int x = lane & 31;
+        if (x < pw) {
+            for (int r = lane >> 5; r < ph; r += 2) {
+                const int a = win[r * kWinW + x], b = win[r * kWinW + x + 1];
+                const int c = win[(r + 1) * kWinW + x], d = win[(r + 1) * kWinW + x + 1];
+                int v;
+                if (mx && my) {
+                    const int t0 = (int16_t)(((16 - mx) * a + mx * b + off1) >> sh1);
+                    const int t1 = (int16_t)(((16 - mx) * c + mx * d + off1) >> sh1);
+                    v = ((16 - my) * t0 + my * t1 + 8) >> 4;
+                } else if (mx) {
+                    v = ((16 - mx) * a + mx * b + off1) >> sh1;
+                } else if (my) {
+                    v = ((16 - my) * a + my * c + off1) >> sh1;
+                } else if (BD > 10) {
+                    v = (a + (1 << (BD - 11))) >> (BD - 10);
+                } else {
+                    v = a << (10 - BD);
+                }
+                L.bil[i][r * kBilP + x] = (int16_t)v;
+            }
+        }
+    }
+    wave_sync();
+    // inter.sad (vvcdsp.c:49): every other row; lane -> column lane & 15, row pairs (lane >> 4) + 4 k
+    const int sx = lane & 15, sr = lane >> 4;
+    auto sad_at = [&](int dx, int dy) {
+        const int16_t *a = L.bil[0] + (dy) * kBilP + dx;                   // (2 + (dy - 2)), (2 + (dx - 2))
+        const int16_t *b = L.bil[1] + (4 - dy) * kBilP + (4 - dx);
+        int acc = 0;
+        if (sx < w)
+            for (int r = sr; 2 * r < h; r += 4)
+                acc += abs((int)a[2 * r * kBilP + sx] - (int)b[2 * r * kBilP + sx]);
+        return wave_sum(acc);
+    };
+    int min_sad = sad_at(2, 2);
+    min_sad -= min_sad >> 2;
+    int min_dx = 2, min_dy = 2;
+    searched = 0;
+    if (min_sad >= w * h) {
+        searched = 1;
+        if (lane == 0)
+            L.sad[12] = min_sad;
+        // 8.5.3.4 array entry selection, scan order dy outer / dx inner, first minimum wins
+        for (int k = 0; k < 25; k++) {
+            if (k == 12)
+                continue;
+            const int dy = k / 5, dx = k - dy * 5;
+            const int s = sad_at(dx, dy);
+            if (lane == 0)
+                L.sad[k] = s;
+            if (s < min_sad) {
+                min_sad = s;
+                min_dx = dx;
+                min_dy = dy;
+            }
+        }
+        wave_sync();
+        int dmv0 = (min_dx - 2) * 16, dmv1 = (min_dy - 2) * 16;
+        if (min_dx != 0 && min_dx != 4 && min_dy != 0 && min_dy != 4) {
+            const int k = min_dy * 5 + min_dx;
+            dmv0 += parametric_mv_refine(L.sad[k - 1], L.sad[k], L.sad[k + 1]);
+            dmv1 += parametric_mv_refine(L.sad[k - 5], L.sad[k], L.sad[k + 5]);
+        }
+        mv[0] = clip3(mv[0] + dmv0, -(1 << 17), (1 << 17) - 1);            // ff_vvc_clip_mv
+        mv[1] = clip3(mv[1] + dmv1, -(1 << 17), (1 << 17) - 1);
+        mv[2] = clip3(mv[2] - dmv0, -(1 << 17), (1 << 17) - 1);
+        mv[3] = clip3(mv[3] - dmv1, -(1 << 17), (1 << 17) - 1);
+    }
+    if (min_sad < 2 * w * h)
+        bdof = 0;
+    min_sad_out = min_sad;
+    wave_sync();                                                            // bil / sad are dead from here on
+}
+
+// apply_bdof (vvc_inter_template.c:288) for one wave: interior = the two 14-bit predictions, ring = bdof_fetch_samples (:101)
+template <int BD>
+__device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLds &L, int lane, int w, int h,
+                                          const int (&v0)[4], const int (&v1)[4], const int (&ox)[2], const int (&oy)[2],
+                                          const int (&fx)[2], const int (&fy)[2], const ClampRect (&rc)[2])
+{
+    using px_t = typename Px<BD>::type;
+    int16_t *smp0 = L.smp[0], *smp1 = L.smp[1];
+    int16_t *gh0 = L.grad[0], *gh1 = L.grad[1], *gv0 = L.grad[2], *gv1 = L.grad[3];
+    {
+        const int x = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+            if (x < w && y < h) {
+                smp0[(y + 1) * kGs + x + 1] = (int16_t)v0[i];
+                smp1[(y + 1) * kGs + x + 1] = (int16_t)v1[i];
+            }
+        }
+    }
+    // ring position (x, y) reads the integer sample at (x + (x_frac >> 3), y + (y_frac >> 3)) of the block
+    const int n = 2 * (w + 2) + 2 * h;
+    for (int e = lane; e < 2 * n; e += 64) {
+        const int p = e >= n, i = e - p * n;
+        int x, y;
+        if (i < w + 2)            { y = -1; x = i - 1; }
+        else if (i < 2 * (w + 2)) { y = h;  x = i - (w + 2) - 1; }
+        else                      { const int k = i - 2 * (w + 2); y = k >> 1; x = (k & 1) ? w : -1; }
+        const uint8_t *plane = (const uint8_t *)(p ? job->ref1 : job->ref0);
+        const int stride = p ? job->ref1_stride : job->ref0_stride;
+        const int xa = clip3(ox[p] + x + (fx[p] >> 3), rc[p].x0, rc[p].x1), ya = clip3(oy[p] + y + (fy[p] >> 3), rc[p].y0, rc[p].y1);
+        const int s = gld<px_t>(plane + (ptrdiff_t)ya * stride + xa * (int)sizeof(px_t));
+        (p ? smp1 : smp0)[(y + 1) * kGs + x + 1] = (int16_t)(s << (14 - BD));
+    }
+    wave_sync();
+    // gradients of the interior (prof_grad_filter :135), lane -> column lane & 15, rows (lane >> 4) + 4 k
+    {
+        const int x = (lane & 15) + 1;
+        if (x <= w)
+            for (int y = (lane >> 4) + 1; y <= h; y += 4) {
+                const int o = y * kGs + x;
+                gh0[o] = (int16_t)((smp0[o + 1] >> 6) - (smp0[o - 1] >> 6));
+                gv0[o] = (int16_t)((smp0[o + kGs] >> 6) - (smp0[o - kGs] >> 6));
+                gh1[o] = (int16_t)((smp1[o + 1] >> 6) - (smp1[o - 1] >> 6));
+                gv1[o] = (int16_t)((smp1[o + kGs] >> 6) - (smp1[o - kGs] >> 6));
+            }
+    }
+    wave_sync();
+    // replicate rings: left / right columns first, then whole top / bottom rows (pad_int16, vvcdsp.c:29)
+    if (lane < h) {
+        const int o = (lane + 1) * kGs;
+        gh0[o] = gh0[o + 1]; gh0[o + w + 1] = gh0[o + w];
+        gh1[o] = gh1[o + 1]; gh1[o + w + 1] = gh1[o + w];
+        gv0[o] = gv0[o + 1]; gv0[o + w + 1] = gv0[o + w];
+        gv1[o] = gv1[o + 1]; gv1[o + w + 1] = gv1[o + w];
+        smp0[o] = smp0[o + 1]; smp0[o + w + 1] = smp0[o + w];
+        smp1[o] = smp1[o + 1]; smp1[o + w + 1] = smp1[o + w];
+    }
+    wave_sync();
+    if (lane < w + 2) {
+        const int t = lane, b = (h + 1) * kGs + lane;
+        gh0[t] = gh0[t + kGs]; gh0[b] = gh0[b - kGs];
+        gh1[t] = gh1[t + kGs]; gh1[b] = gh1[b - kGs];
+        gv0[t] = gv0[t + kGs]; gv0[b] = gv0[b - kGs];
+        gv1[t] = gv1[t + kGs]; gv1[b] = gv1[b - kGs];
+        smp0[t] = smp0[t + kGs]; smp0[b] = smp0[b - kGs];
+        smp1[t] = smp1[t + kGs]; smp1[b] = smp1[b - kGs];
+    }
+    wave_sync();
+    // 16 lanes per 4x4 sub-block, four sub-blocks per pass (derive_bdof_vx_vy :237, apply_bdof_min_block :267)
+    const int sbw = w >> 2, nsb = sbw * (h >> 2), l = lane & 15;
+    uint8_t *dst = (uint8_t *)job->dst;
+    for (int sb = lane >> 4; sb < nsb; sb += 4) {
+        const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
+        int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
+        for (int e = l; e < 36; e += 16) {
+            const int j = e / 6, i = e - j * 6;
+            const int o = (by + j) * kGs + bx + i;
+            const int diff = (smp0[o] >> 4) - (smp1[o] >> 4);
+            const int th = (gh0[o] + gh1[o]) >> 1;
+            const int tv = (gv0[o] + gv1[o]) >> 1;
+            sgx2 += abs(th);
+            sgy2 += abs(tv);
+            sgxgy += sign_of(tv) * th;
+            sgxdi += -sign_of(th) * diff;
+            sgydi += -sign_of(tv) * diff;
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            sgx2 += __shfl_xor(sgx2, m, 16);
+            sgy2 += __shfl_xor(sgy2, m, 16);
+            sgxgy += __shfl_xor(sgxgy, m, 16);
+            sgxdi += __shfl_xor(sgxdi, m, 16);
+            sgydi += __shfl_xor(sgydi, m, 16);
+        }
+        const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;
+        const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
+        const int py = by + (l >> 2), px = bx + (l & 3);
+        const int o = (py + 1) * kGs + px + 1;
+        const int sh = 15 - BD, off = 1 << (sh - 1);
+        const int corr = vx * (gh0[o] - gh1[o]) + vy * (gv0[o] - gv1[o]);
+        st_px<BD>(dst + (ptrdiff_t)py * job->dst_stride, px, clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh));
+    }
+}
+
+// both references at motion mv: windows through clamped coordinates, then the separable interpolation of interp_block
+template <int BD, int NTAP>
+__device__ __forceinline__ void predict_clamped(const vvc355_bipred_job *job, BipredLds &L, int lane, int lw, int h,
+                                                const int (&ox)[2], const int (&oy)[2], const int (&fx)[2], const int (&fy)[2],
+                                                const ClampRect (&rc)[2], int (&v0)[4], int (&v1)[4])
+{
+    constexpr int LEAD = NTAP == 8 ? 3 : 1, NIT = (16 + NTAP) / 2;
+    {
+        uint16_t r0[NIT], r1[NIT];
+        fetch_clamped<BD, NIT>((const uint8_t *)job->ref0, job->ref0_stride, rc[0], ox[0] - LEAD, oy[0] - (fy[0] ? LEAD : 0), lane, r0);
+        fetch_clamped<BD, NIT>((const uint8_t *)job->ref1, job->ref1_stride, rc[1], ox[1] - LEAD, oy[1] - (fy[1] ? LEAD : 0), lane, r1);
+        store_rows<NIT>(L.win[0], lane, r0);
+        store_rows<NIT>(L.win[1], lane, r1);
+        wave_sync();
+    }
+    uint32_t t[2][4];       // hf lo/hi, vf lo/hi per reference
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (NTAP == 8) {
+            const uint2 hf = gld<uint2>(d_tab_inter_luma_filters + (job->hf_idx * 16 + fx[i]) * 8);
+            const uint2 vf = gld<uint2>(d_tab_inter_luma_filters + (job->vf_idx * 16 + fy[i]) * 8);
+            t[i][0] = hf.x; t[i][1] = hf.y; t[i][2] = vf.x; t[i][3] = vf.y;
+        } else {
+            t[i][0] = gld<uint32_t>(d_tab_inter_chroma_filters + (job->hf_idx * 32 + fx[i]) * 4); t[i][1] = 0;
+            t[i][2] = gld<uint32_t>(d_tab_inter_chroma_filters + (job->vf_idx * 32 + fy[i]) * 4); t[i][3] = 0;
+        }
+    }
+    interp_block<BD, NTAP>(lw, h, fx[0] != 0, fy[0] != 0, t[0][0], t[0][1], t[0][2], t[0][3], L.win[0], L.tmpT, lane, v0);
+    interp_block<BD, NTAP>(lw, h, fx[1] != 0, fy[1] != 0, t[1][0], t[1][1], t[1][2], t[1][3], L.win[1], L.tmpT, lane, v1);
+}
+
+template <int BD>
+__global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
+{
+    __shared__ __attribute__((aligned(16))) BipredLds lds_all[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ji = blockIdx.x * 4 + wave;
+    if (ji >= n_jobs)
+        return;
+    const vvc355_bipred_job *job = jobs + ji;            // wave-uniform
+    BipredLds &L = lds_all[wave];
+    const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr;
+    const int lw = 31 - __builtin_clz(w);
+    vvc355_bipred_result *rec = (vvc355_bipred_result *)job->rec;
+    int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
+    int bdof = !chroma && job->bdof;
+    if (chroma && rec) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mv[k] = gld<int>(&rec->mv[k]);
+    }
+    if (!chroma) {
+        int min_sad = 0, searched = 0;
+        if (dmvr)
+            dmvr_refine<BD>(job, L, lane, mv, bdof, min_sad, searched);
+        if (rec && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) gst<int>(&rec->mv[k], mv[k]);
+            gst<int>(&rec->bdof, bdof);
+            gst<int>(&rec->min_sad, min_sad);
+            gst<int>(&rec->searched, searched);
+        }
+    }
+    // integer positions, fractions, readable rectangles (luma_mc_bi :262-283 / chroma_mc_bi :344-362, emulated_edge* :33-88)
+    const int before = chroma ? 1 : 3, after = chroma ? 2 : 4;
+    const int shx = 4 + (chroma ? job->hs : 0), shy = 4 + (chroma ? job->vs : 0);
+    int ox[2], oy[2], fx[2], fy[2];
+    ClampRect rc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int mvx = mv[2 * i], mvy = mv[2 * i + 1];
+        fx[i] = chroma ? (mvx & ((1 << shx) - 1)) << (1 - job->hs) : mvx & 15;
+        fy[i] = chroma ? (mvy & ((1 << shy) - 1)) << (1 - job->vs) : mvy & 15;
+        ox[i] = job->x + (mvx >> shx);
+        oy[i] = job->y + (mvy >> shy);
+        rc[i] = ClampRect{ 0, 0, job->pic_w - 1, job->pic_h - 1 };
+        if (dmvr) {
+            const int x_sb = job->x + (job->mv[2 * i] >> shx), y_sb = job->y + (job->mv[2 * i + 1] >> shy);
+            rc[i].x0 = min(max(x_sb - before, 0), job->pic_w - 1);
+            rc[i].y0 = min(max(y_sb - before, 0), job->pic_h - 1);
+            rc[i].x1 = rc[i].x0 + max(min((int)job->pic_w, x_sb + w + after) - rc[i].x0, 1) - 1;
+            rc[i].y1 = rc[i].y0 + max(min((int)job->pic_h, y_sb + h + after) - rc[i].y0, 1) - 1;
+        }
+    }
+    int v0[4], v1[4];
+    if (chroma)
+        predict_clamped<BD, 4>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1);
+    else
+        predict_clamped<BD, 8>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v0[i] = (int16_t)v0[i]; v1[i] = (int16_t)v1[i]; }     // put[..] stores int16
+    if (bdof) {
+        bdof_wave<BD>(job, L, lane, w, h, v0, v1, ox, oy, fx, fy, rc);
+        return;
+    }
+    int shift, off;
+    const int wf = job->weight_flag, w0 = job->w0, w1 = job->w1;
+    if (!wf) { shift = max(3, 15 - BD); off = 1 << (shift - 1); }                                                   // avg
+    else     { shift = job->denom + max(3, 15 - BD); off = (((job->o0 + job->o1) << (BD - 8)) + 1) << (shift - 1); } // w_avg
+    const int x = lane & 15;
+    uint8_t *dst = (uint8_t *)job->dst;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+        if (x >= w || y >= h)
+            continue;
+        const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
+        st_px<BD>(dst + (ptrdiff_t)y * job->dst_stride, x, clip_px<BD>(p));
+    }
+}
+
 } // namespace vvc355
 
 extern "C" void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_job *jobs_dev, int n_jobs)
@@ -252,5 +656,13 @@ extern "C" void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_
     using namespace vvc355;
     if (n_jobs <= 0) return;
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((pred_fused_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs)
+{
+    using namespace vvc355;
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
     HIP_CHECK(hipGetLastError());
 }

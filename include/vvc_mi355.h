@@ -252,6 +252,34 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
  * (vvc_intra.c:464-472 via itx_2d, vvcdsp.c:94) is what a caller bins by tb size to fill these launches. */
 void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_w, int log2_h);
 
+/*
+ * Scaling process for transform coefficients (dequant) — NOT a table slot in the reference: host C in
+ * vvc_intra.c:277-417 (derive_qp :277, derive_scale :311, derive_scale_m :341, scale_coeff :391, dequant :400),
+ * called per transform block right before LFNST / itx (vvc_intra.c:455-462).  Flattened: everything read through
+ * VVCLocalContext arrives as plain numbers.
+ *   qp            = tb->qp as derive_qp leaves it (CU qp + offsets, clipped; :291-303)
+ *   ts            = tb->ts (transform skip: bd_shift 10, no rectangular correction, no dep-quant add-in)
+ *   dep_quant     = sh_dep_quant_used_flag
+ *   scale_matrix  = 0 for the flat default (every factor 16, ff_vvc_default_scale_m), else ScalingMatrixRec[id]
+ *                   (uint8, (1 << log2_matrix_size)^2 entries) of the matrix derive_scale_m selects (:343-371)
+ *   dc            = ScalingMatrixDcRec value replacing the factor of coefficient (0,0) when id >= 14 and the scan
+ *                   rectangle starts at the origin (:380-381); negative = none
+ *   min/max_x/y   = tb->min_scan_x .. max_scan_y, the rectangle holding non-zero levels
+ * In place on int32 coeffs[h][w]: c = clip_intp2((c * scale * m + bd_offset) >> bd_shift, range) for c != 0.
+ */
+typedef struct vvc355_dequant_job {
+    uint64_t coeffs;
+    uint64_t scale_matrix;
+    uint8_t  log2_w, log2_h, min_x, min_y, max_x, max_y;
+    uint8_t  qp, ts, dep_quant, bit_depth, range, log2_matrix_size;
+    int16_t  dc;
+    uint8_t  pad_[2];
+} vvc355_dequant_job;
+
+void vvc355_dequant_batch(void *stream, const vvc355_dequant_job *jobs_dev, int n_jobs);
+void vvc355_dequant(int *coeffs, int log2_w, int log2_h, int min_x, int min_y, int max_x, int max_y, int qp, int ts,
+    int dep_quant, int bit_depth, int log2_transform_range, const uint8_t *scale_matrix, int log2_matrix_size, int dc);
+
 /* VVCItxDSPContext.itx[trh][trv][log2 w][log2 h] — vvcdsp.h:118, vvcdsp.c:94-195.  Returns -1 (nothing done) for a
  * combination the reference table leaves NULL (vvcdsp_template.c:142-159), else 0. */
 int  vvc355_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
@@ -363,6 +391,44 @@ typedef struct vvc355_pred_job {
 } vvc355_pred_job;
 
 void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_job *jobs_dev, int n_jobs);
+
+/* ------------------------------------------------------------------ regular bi-prediction incl. its callers (mc_fused.hip) */
+
+/*
+ * One regular bi-predicted sub-block (<= 16x16 in its own component) together with the caller work the reference does
+ * around the slots, vvc_inter.c:772-822 (pred_regular_blk):
+ *   luma   (chroma = 0): derive_sb_mv -> dmvr_mv_refine (:685-748: inter.dmvr[..] x2, 25 x inter.sad, parametric_mv_refine
+ *          :642-681, ff_vvc_clip_mv), then luma_mc_bi (:253-296): put[..] x2 at the refined motion, bdof_fetch_samples +
+ *          apply_bdof, or w_avg / avg.  The refined motion and the sub-block BDOF decision go to *rec.
+ *   chroma (chroma = 1): chroma_mc_bi (:330-369) at the motion found in *rec (rec = 0: at mv), avg / w_avg.
+ * Edge emulation (:33-110) is done by reading the reference planes at clamped coordinates: to the picture, or with
+ * dmvr != 0 to the window of the unrefined block (emulated_edge_dmvr :61-88).  Planes need no padding.
+ *   ref0 / ref1  DEVICE address of sample (0, 0) of this component in the two reference pictures
+ *   mv           mvf->mv[L0].x, .y, mvf->mv[L1].x, .y in 1/16 luma samples, as parsed (the "orig_mv" of the reference)
+ *   x, y, w, h   position and size in this component's samples; pic_w, pic_h likewise
+ *   hf_idx/vf_idx  filter set (vvc_inter.c:382-383: 0 regular, 1 half-sample alternative)
+ *   weight_flag, denom, w0, w1, o0, o1   what derive_weight (:137-167) returns for this component
+ * Launch the luma jobs of a frame first, then the chroma jobs that point at their records.
+ */
+typedef struct vvc355_bipred_job {
+    uint64_t dst, ref0, ref1, rec;
+    int32_t  dst_stride, ref0_stride, ref1_stride;      /* bytes */
+    int32_t  mv[4];
+    int16_t  x, y, w, h, pic_w, pic_h;
+    int16_t  denom, w0, w1, o0, o1;
+    uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
+    uint8_t  pad_[6];
+} vvc355_bipred_job;
+
+typedef struct vvc355_bipred_result {
+    int32_t mv[4];            /* motion after refinement (what set_dmvr_info stores, vvc_inter.c:750-762) */
+    int32_t bdof;             /* sb_bdof_flag after the DMVR early termination rule (:744-746) */
+    int32_t min_sad;          /* minimum SAD of the search (centre: after the 3/4 scaling), dmvr jobs only */
+    int32_t searched;         /* 0 when the centre SAD ended the search early (:712) */
+    int32_t pad_;
+} vvc355_bipred_result;
+
+void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs);
 
 #ifdef __cplusplus
 }

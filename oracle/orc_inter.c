@@ -348,3 +348,156 @@ ORC_API void orc_dmvr(int bd, int vfrac, int hfrac, int16_t *dst, const uint8_t 
             dst[y * ORC_PB + x] = (int16_t)v;
         }
 }
+
+
+/* ------------------------------------------------------------------ callers: one regular bi-predicted sub-block
+ *
+ * What pred_regular_blk (vvc_inter.c:772-822) does per sub-block around the slots above: derive_sb_mv -> dmvr_mv_refine
+ * (:685-748, parametric_mv_refine :642-681), then luma_mc_bi (:253-296) and chroma_mc_bi (:330-369) with their edge
+ * emulation (:33-110; libavcodec/videodsp_template.c:28 replicates the nearest sample of the allowed rectangle, i.e. it
+ * reads the plane at clamped coordinates).  Flattened: planes, position, motion and flags arrive in orc_bipred_job.
+ */
+extern const int8_t orc_tab_inter_luma_filters[3 * 16 * 8], orc_tab_inter_chroma_filters[3 * 32 * 4];
+
+#define EMU_STRIDE (ORC_PB + 32)                 /* EDGE_EMU_BUFFER_STRIDE, vvc_ctu.h */
+
+/* emulated_edge_mc restated: window of bw x bh samples whose top-left is plane sample (x0, y0), every coordinate clamped to
+ * [cx0, cx1] x [cy0, cy1]; buf is pixel-typed with EMU_STRIDE samples per row */
+static void emu_window(int wide, uint8_t *buf, const uint8_t *plane, ptrdiff_t stride_bytes, int x0, int y0, int bw, int bh,
+                       int cx0, int cy0, int cx1, int cy1)
+{
+    const ptrdiff_t ss = stride_bytes >> wide;
+    for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+            const int sx = orc_clip3(x0 + x, cx0, cx1), sy = orc_clip3(y0 + y, cy0, cy1);
+            orc_st(buf, (ptrdiff_t)y * EMU_STRIDE + x, orc_ld(plane, (ptrdiff_t)sy * ss + sx, wide), wide);
+        }
+}
+
+/* vvc_inter.c:642-681 */
+static int parametric_mv_refine(const int *sad, int stride)
+{
+    const int sad_minus = sad[-stride], sad_center = sad[0], sad_plus = sad[stride];
+    int denom = ((sad_minus + sad_plus) - (sad_center << 1)) << 3;
+    if (!denom)
+        return 0;
+    if (sad_minus == sad_center)
+        return -8;
+    if (sad_plus == sad_center)
+        return 8;
+    int num = (sad_minus - sad_plus) * (1 << 4), sign_num = 0, quotient = 0;
+    if (num < 0) {
+        num = -num;
+        sign_num = 1;
+    }
+    for (int counter = 3; counter > 0; counter--) {
+        quotient <<= 1;
+        if (num >= denom) {
+            num -= denom;
+            quotient++;
+        }
+        denom >>= 1;
+    }
+    return sign_num ? -quotient : quotient;
+}
+
+ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
+{
+    const int wide = bd > 8;
+    const int w = job->w, h = job->h, chroma = job->chroma;
+    const uint8_t *ref[2] = { (const uint8_t *)(uintptr_t)job->ref0, (const uint8_t *)(uintptr_t)job->ref1 };
+    const ptrdiff_t rstride[2] = { job->ref0_stride, job->ref1_stride };
+    orc_bipred_result *rec = (orc_bipred_result *)(uintptr_t)job->rec;
+    int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
+    int bdof = !chroma && job->bdof;
+    static _Thread_local int16_t tmpbuf[2][(ORC_PB + 4) * ORC_PB];
+    static _Thread_local uint8_t emu[2 * EMU_STRIDE * (ORC_PB + 8)];
+
+    if (chroma && rec) {
+        /* chroma follows the luma block's refined motion (vvc_inter.c:622-628: mv is the one derive_sb_mv refined) */
+        for (int k = 0; k < 4; k++) mv[k] = rec->mv[k];
+    }
+    if (!chroma && job->dmvr) {
+        /* dmvr_mv_refine, vvc_inter.c:685-748 */
+        int sad[5][5], min_dx = 2, min_dy = 2, min_sad, searched = 0;
+        for (int i = 0; i < 2; i++) {
+            const int pred_w = w + 4, pred_h = h + 4;
+            const int mx = mv[2 * i] & 15, my = mv[2 * i + 1] & 15;
+            const int ox = job->x + (mv[2 * i] >> 4) - 2, oy = job->y + (mv[2 * i + 1] >> 4) - 2;
+            emu_window(wide, emu, ref[i], rstride[i], ox, oy, pred_w + 1, pred_h + 1, 0, 0, job->pic_w - 1, job->pic_h - 1);
+            orc_dmvr(bd, !!my, !!mx, tmpbuf[i], emu, (ptrdiff_t)EMU_STRIDE << wide, pred_h, mx, my, pred_w);
+        }
+        min_sad = orc_sad(tmpbuf[0], tmpbuf[1], 2, 2, w, h);
+        min_sad -= min_sad >> 2;
+        sad[2][2] = min_sad;
+        if (min_sad >= w * h) {
+            int dmv[2];
+            searched = 1;
+            for (int dy = 0; dy < 5; dy++)
+                for (int dx = 0; dx < 5; dx++)
+                    if (dx != 2 || dy != 2) {
+                        sad[dy][dx] = orc_sad(tmpbuf[0], tmpbuf[1], dx, dy, w, h);
+                        if (sad[dy][dx] < min_sad) {
+                            min_sad = sad[dy][dx];
+                            min_dx = dx;
+                            min_dy = dy;
+                        }
+                    }
+            dmv[0] = (min_dx - 2) * 16;
+            dmv[1] = (min_dy - 2) * 16;
+            if (min_dx != 0 && min_dx != 4 && min_dy != 0 && min_dy != 4) {
+                dmv[0] += parametric_mv_refine(&sad[min_dy][min_dx], 1);
+                dmv[1] += parametric_mv_refine(&sad[min_dy][min_dx], 5);
+            }
+            for (int i = 0; i < 2; i++) {
+                mv[2 * i] = orc_clip3(mv[2 * i] + (1 - 2 * i) * dmv[0], -(1 << 17), (1 << 17) - 1);           /* ff_vvc_clip_mv */
+                mv[2 * i + 1] = orc_clip3(mv[2 * i + 1] + (1 - 2 * i) * dmv[1], -(1 << 17), (1 << 17) - 1);
+            }
+        }
+        if (min_sad < 2 * w * h)
+            bdof = 0;
+        if (rec) {
+            rec->min_sad = min_sad;
+            rec->searched = searched;
+        }
+    }
+    if (!chroma && rec) {
+        for (int k = 0; k < 4; k++) rec->mv[k] = mv[k];
+        rec->bdof = bdof;
+    }
+
+    /* luma_mc_bi :253-296 / chroma_mc_bi :330-369 */
+    const int before = chroma ? 1 : 3, after = chroma ? 2 : 4, extra = before + after;
+    const int shx = 4 + (chroma ? job->hs : 0), shy = 4 + (chroma ? job->vs : 0);
+    int16_t *tmp[2] = { tmpbuf[0] + 2 * ORC_PB + 32, tmpbuf[1] + 2 * ORC_PB + 32 };      /* room for the BDOF ring */
+    for (int i = 0; i < 2; i++) {
+        const int mvx = mv[2 * i], mvy = mv[2 * i + 1];
+        const int mx = chroma ? (mvx & ((1 << shx) - 1)) << (1 - job->hs) : mvx & 15;
+        const int my = chroma ? (mvy & ((1 << shy) - 1)) << (1 - job->vs) : mvy & 15;
+        const int ox = job->x + (mvx >> shx), oy = job->y + (mvy >> shy);
+        const int8_t *hf = chroma ? orc_tab_inter_chroma_filters + (job->hf_idx * 32 + mx) * 4 : orc_tab_inter_luma_filters + (job->hf_idx * 16 + mx) * 8;
+        const int8_t *vf = chroma ? orc_tab_inter_chroma_filters + (job->vf_idx * 32 + my) * 4 : orc_tab_inter_luma_filters + (job->vf_idx * 16 + my) * 8;
+        int cx0 = 0, cy0 = 0, cx1 = job->pic_w - 1, cy1 = job->pic_h - 1;
+        if (job->dmvr) {
+            /* emulated_edge_dmvr :61-88: the readable rectangle is the window of the UNREFINED block */
+            const int x_sb = job->x + (job->mv[2 * i] >> shx), y_sb = job->y + (job->mv[2 * i + 1] >> shy);
+            cx0 = orc_min(orc_max(x_sb - before, 0), job->pic_w - 1);
+            cy0 = orc_min(orc_max(y_sb - before, 0), job->pic_h - 1);
+            cx1 = cx0 + orc_max(orc_min(job->pic_w, x_sb + w + after) - cx0, 1) - 1;
+            cy1 = cy0 + orc_max(orc_min(job->pic_h, y_sb + h + after) - cy0, 1) - 1;
+        }
+        uint8_t *buf = emu + (size_t)i * EMU_STRIDE * (ORC_PB + 8);
+        emu_window(wide, buf, ref[i], rstride[i], ox - before, oy - before, w + extra, h + extra, cx0, cy0, cx1, cy1);
+        const uint8_t *src = buf + (((ptrdiff_t)before * EMU_STRIDE + before) << wide);
+        orc_put(bd, chroma, !!my, !!mx, tmp[i], src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
+        if (bdof)
+            orc_bdof_fetch_samples(bd, tmp[i], src, (ptrdiff_t)EMU_STRIDE << wide, mx, my, w, h);
+    }
+    uint8_t *dst = (uint8_t *)(uintptr_t)job->dst;
+    if (bdof)
+        orc_apply_bdof(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h);
+    else if (job->weight_flag)
+        orc_w_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h, job->denom, job->w0, job->w1, job->o0, job->o1);
+    else
+        orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h);
+}

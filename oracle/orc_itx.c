@@ -184,3 +184,36 @@ ORC_API void orc_transform_bdpcm(int *coeffs, int width, int height, int vertica
                 coeffs[y * width + x] = orc_clip_intp2(coeffs[y * width + x] + coeffs[y * width + x - 1], log2_transform_range);
     }
 }
+
+/* vvc_intra.c:277-417 — scaling process for transform coefficients (dequant), flattened as in include/vvc_mi355.h:
+ * derive_qp's bd_shift / rect_non_ts_flag (:297-309), derive_scale (:311-338), derive_scale_m's up-sampling and DC
+ * override (:373-381), scale_coeff (:391-397), the loop of dequant (:410-417). */
+ORC_API void orc_dequant(int *coeffs, int log2_w, int log2_h, int min_x, int min_y, int max_x, int max_y, int qp, int ts,
+                         int dep_quant, int bit_depth, int log2_transform_range, const uint8_t *scale_matrix,
+                         int log2_matrix_size, int dc)
+{
+    static const int level_scale[2][6] = { { 40, 45, 51, 57, 64, 72 }, { 57, 64, 72, 80, 90, 102 } };
+    const int log_sum = log2_w + log2_h;
+    const int rect = ts ? 0 : (log_sum & 1);
+    const int bd_shift = ts ? 10 : bit_depth + rect + log_sum / 2 + 10 - log2_transform_range + dep_quant;
+    const int bd_offset = (1 << bd_shift) >> 1;
+    const int q = qp + ((dep_quant && !ts) ? 1 : 0);
+    const int scale = level_scale[rect][q % 6] << (q / 6);
+    int first = 1;
+    for (int y = min_y; y <= max_y; y++) {
+        for (int x = min_x; x <= max_x; x++) {
+            int *c = coeffs + (y << log2_w) + x;
+            int m = 16;
+            if (scale_matrix) {
+                const int off = y << log2_matrix_size >> log2_h << log2_matrix_size;
+                m = scale_matrix[off + (x << log2_matrix_size >> log2_w)];
+                if (first && dc >= 0 && !min_x && !min_y)
+                    m = dc;
+            }
+            first = 0;
+            if (*c)
+                *c = orc_clip_intp2((int)((unsigned)*c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift,
+                                    log2_transform_range);
+        }
+    }
+}

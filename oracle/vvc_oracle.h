@@ -85,6 +85,9 @@ enum { ORC_DCT2 = 0, ORC_DST7 = 1, ORC_DCT8 = 2 };
 /* 1-D kernels on a strided int vector; n = 1,2,4,..,64 (DCT2) or 1,4,8,16,32 (DST7/DCT8) */
 void orc_inv_tx_1d(int type, int n, int *coeffs, ptrdiff_t stride, size_t nz);
 /* itx.itx[trh][trv][log2 w][log2 h]; returns 0, or -1 when the reference table has no entry for that combination */
+void orc_dequant(int *coeffs, int log2_w, int log2_h, int min_x, int min_y, int max_x, int max_y, int qp, int ts,
+                 int dep_quant, int bit_depth, int log2_transform_range, const uint8_t *scale_matrix,
+                 int log2_matrix_size, int dc);
 int  orc_itx(int trh, int trv, int log2_w, int log2_h, int *coeffs, size_t nzw, size_t nzh,
     intptr_t log2_transform_range, intptr_t bd);
 void orc_inv_lfnst_1d(int *v, const int *u, int no_zero_size, int n_tr_s, int pred_mode_intra, int lfnst_idx,
@@ -96,6 +99,23 @@ void orc_transform_bdpcm(int *coeffs, int width, int height, int vertical, int l
 
 /* ---- intra (orc_intra.c).  Leaf predictors: `stride` counts PIXELS, like the reference's POS() macro. ---- */
 /* intra_pred with VVCLocalContext flattened; same layout as vvc355_intra_job (include/vvc_mi355.h), plane = HOST address */
+/* ---- one regular bi-predicted sub-block incl. its callers' work (orc_inter.c, "pred_regular_blk") ----
+ * Same layout as vvc355_bipred_job / vvc355_bipred_result of include/vvc_mi355.h, with host addresses. */
+typedef struct orc_bipred_job {
+    uint64_t dst, ref0, ref1, rec;
+    int32_t  dst_stride, ref0_stride, ref1_stride;
+    int32_t  mv[4];
+    int16_t  x, y, w, h, pic_w, pic_h;
+    int16_t  denom, w0, w1, o0, o1;
+    uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
+    uint8_t  pad_[6];
+} orc_bipred_job;
+typedef struct orc_bipred_result {
+    int32_t mv[4];
+    int32_t bdof, min_sad, searched, pad_;
+} orc_bipred_result;
+void orc_bipred_block(int bd, const orc_bipred_job *job);
+
 typedef struct orc_intra_job {
     uint64_t plane;
     int32_t  stride;

@@ -1,0 +1,112 @@
+"""GPU parity of the regular bi-prediction stage (DMVR search + refined 8-tap MC + BDOF / avg / w_avg, chroma at the refined
+motion, edge emulation by clamped reads) vs the oracle's restatement of pred_regular_blk (vvc_inter.c:685-822)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import bipred_cases as bc
+from conftest import P
+from ffvvc_amd import abi, batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_bipred_frame(dev, orc, bd):
+    bc.bind_oracle(orc)
+    rng = np.random.default_rng(0x5EED0800 + bd)
+    pw, ph = 208, 144
+    isz = 1 if bd == 8 else 2
+    base = [bc.smooth_picture(rng, ph, pw, bd), bc.smooth_picture(rng, ph // 2, pw // 2, bd), bc.smooth_picture(rng, ph // 2, pw // 2, bd)]
+    # reference 1 = reference 0 displaced by a small whole-sample motion plus noise: the search has something to find
+    refs = [[p.copy() for p in base], []]
+    for c, p in enumerate(base):
+        noise = rng.integers(-3, 4, size=p.shape)
+        noise[:, :3 * p.shape[1] // 4] = 0        # left three quarters: an exact displaced copy (zero-cost matches exist)
+        q = bc.shifted(p, 2 >> (c > 0), -2 >> (c > 0)).astype(np.int64) + noise
+        refs[1].append(np.clip(q, 0, (1 << bd) - 1).astype(p.dtype))
+    dims = [(pw, ph), (pw // 2, ph // 2), (pw // 2, ph // 2)]
+    blocks = bc.random_blocks(rng, pw, ph)
+    n = len(blocks)
+
+    want = [np.full((d[1], d[0]), 0x21, base[0].dtype) for d in dims]
+    want_rec = (abi.BipredResult * n)()
+    d_out = [batch.DeviceBuffer.from_host(w_) for w_ in want]
+    d_refs = [[batch.DeviceBuffer.from_host(p) for p in r] for r in refs]
+    d_rec = batch.DeviceBuffer.from_host(np.zeros(n * 32, np.uint8))
+    luma = (abi.BipredJob * n)()
+    chroma = (abi.BipredJob * (2 * n))()
+    host_jobs = []
+    for i, (x, y, w, h) in enumerate(blocks):
+        kind = i % 5
+        if kind == 0:      # motion that matches the displacement between the references (+- a sample): deep minima, early outs
+            mv0 = [int(rng.integers(-40, 41)), int(rng.integers(-40, 41))]
+            # ref1[y, x] = ref0[y - 2, x + 2]: equal predictions at mv1 = mv0 + (-2, +2) samples; one sample off is found by the search
+            mv1 = [mv0[0] - 32 + int(rng.integers(-1, 2)) * 16, mv0[1] + 32 + int(rng.integers(-1, 2)) * 16]
+        elif kind == 1:    # far outside the picture: every read is an emulated edge
+            mv0 = [int(rng.integers(-4000, 4000)), int(rng.integers(-3000, 3000))]
+            mv1 = [int(rng.integers(-4000, 4000)), int(rng.integers(-3000, 3000))]
+        else:
+            mv0 = [int(v) for v in rng.integers(-200, 201, size=2)]
+            mv1 = [int(v) for v in rng.integers(-200, 201, size=2)]
+        dmvr = int(rng.random() < 0.7)
+        bdof = int(rng.random() < 0.6)
+        if kind == 0:
+            dmvr = bdof = 1
+        wf = int(rng.random() < 0.3 and not dmvr)
+        for c in range(3):
+            j = abi.BipredJob()
+            sh = 1 if c else 0
+            j.x, j.y, j.w, j.h = x >> sh, y >> sh, w >> sh, h >> sh
+            j.pic_w, j.pic_h = dims[c]
+            for k, v in enumerate(mv0 + mv1):
+                j.mv[k] = v
+            j.chroma, j.hs, j.vs = int(c > 0), 1, 1
+            j.dmvr, j.bdof, j.weight_flag = dmvr, bdof, wf
+            j.hf_idx = j.vf_idx = int(rng.integers(0, 2)) if c == 0 else 0
+            if c:
+                j.hf_idx, j.vf_idx = host_jobs[-c][0].hf_idx, host_jobs[-c][0].vf_idx
+            j.denom = int(rng.integers(0, 8))
+            j.w0, j.w1, j.o0, j.o1 = (int(v) for v in rng.integers(-128, 128, size=4))
+            j.dst_stride = j.ref0_stride = j.ref1_stride = dims[c][0] * isz
+            host_jobs.append((j, c, i))
+
+    # ---- oracle, in the reference's order: luma block (refines), then its chroma blocks
+    for (j, c, i) in host_jobs:
+        hj = abi.BipredJob.from_buffer_copy(j)
+        hj.dst = P(want[c], hj.y * dims[c][0] + hj.x)
+        hj.ref0, hj.ref1 = P(refs[0][c]), P(refs[1][c])
+        hj.rec = ctypes.addressof(want_rec[i])
+        orc.orc_bipred_block(bd, ctypes.byref(hj))
+
+    # ---- device: all luma jobs in one launch, then all chroma jobs
+    nl = nc = 0
+    for (j, c, i) in host_jobs:
+        dj = abi.BipredJob.from_buffer_copy(j)
+        dj.dst = d_out[c].ptr + (dj.y * dims[c][0] + dj.x) * isz
+        dj.ref0, dj.ref1 = d_refs[0][c].ptr, d_refs[1][c].ptr
+        dj.rec = d_rec.ptr + 32 * i
+        if c == 0:
+            luma[nl] = dj; nl += 1
+        else:
+            chroma[nc] = dj; nc += 1
+    d_l, d_c = batch.jobs_to_device(luma), batch.jobs_to_device(chroma)
+    dev.vvc355_bipred_batch(None, bd, d_l.ptr, nl)
+    dev.vvc355_bipred_batch(None, bd, d_c.ptr, nc)
+    dev.vvc355_stream_sync(None)
+
+    got_rec = d_rec.to_host(np.int32, (n, 8))
+    exp_rec = np.frombuffer(bytes(want_rec), np.int32).reshape(n, 8)
+    bad = np.argwhere(got_rec[:, :7] != exp_rec[:, :7])
+    assert len(bad) == 0, f"record of block {bad[0][0]} {blocks[bad[0][0]]}: got {got_rec[bad[0][0]].tolist()} want {exp_rec[bad[0][0]].tolist()}"
+    for c in range(3):
+        got = d_out[c].to_host(want[c].dtype, want[c].shape)
+        bad = np.argwhere(got != want[c])
+        assert len(bad) == 0, f"component {c}: {len(bad)} samples differ, first at {bad[0].tolist()}"
+    # the case mix must reach every branch: searches, early terminations, BDOF on and switched off by DMVR
+    dm = np.array([hj[0].dmvr for hj in host_jobs[::3]], bool)
+    assert np.any(exp_rec[dm, 6] == 1) and np.any(exp_rec[dm, 6] == 0)
+    bd_in = np.array([hj[0].bdof for hj in host_jobs[::3]], bool)
+    assert np.any(exp_rec[bd_in, 4] == 1) and np.any((exp_rec[:, 4] == 0) & bd_in & dm)
+    assert np.any(np.any(exp_rec[:, :4] != np.array([[*hj[0].mv] for hj in host_jobs[::3]]), axis=1))

@@ -156,3 +156,62 @@ def test_itx_batches_with_residual_add(dev, orc, bd):
 def test_itx_shape_batch_falls_back_exactly(dev, orc):
     rng = np.random.default_rng(0x5EED0440)
     _itx_frame_case(dev, orc, 10, rng, [(2, 2), (3, 3), (4, 4), (5, 5), (6, 6), (3, 5), (6, 4), (5, 6), (3, 6), (5, 4)], 300, wild=True)
+
+
+def _dequant_cases(rng, n):
+    """Random flattened dequant calls in the domain derive_qp / derive_scale_m allow (vvc_intra.c:277-381)."""
+    for _ in range(n):
+        lw, lh = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+        w, h = 1 << lw, 1 << lh
+        bd = int(rng.choice([8, 10, 12]))
+        min_x, min_y = int(rng.integers(0, min(w, 4))), int(rng.integers(0, min(h, 4)))
+        max_x, max_y = int(rng.integers(min_x, min(w, 32))), int(rng.integers(min_y, min(h, 32)))
+        if rng.random() < 0.5:
+            min_x = min_y = 0
+        ts = int(rng.random() < 0.2)
+        dep = int(rng.integers(0, 2))
+        qp = int(rng.integers(0, 63 + 6 * (bd - 8) + 1))
+        use_list = rng.random() < 0.5
+        lm = int(rng.choice([1, 2, 3]))
+        sm = rng.integers(1, 256, size=(1 << (2 * lm),)).astype(np.uint8) if use_list else None
+        dc = int(rng.integers(1, 256)) if (use_list and rng.random() < 0.5) else -1
+        c = rng.integers(-(1 << 15), 1 << 15, size=(h, w)).astype(np.int32)
+        c[rng.random((h, w)) < 0.4] = 0
+        yield lw, lh, min_x, min_y, max_x, max_y, qp, ts, dep, bd, 15, sm, lm, dc, c
+
+
+def test_dequant(dev, orc):
+    rng = np.random.default_rng(0x5EED0450)
+    n = 0
+    for (lw, lh, x0, y0, x1, y1, qp, ts, dep, bd, rg, sm, lm, dc, c) in _dequant_cases(rng, 300):
+        a, b = c.copy(), c.copy()
+        smp = P(sm) if sm is not None else None
+        orc.orc_dequant(P(a), lw, lh, x0, y0, x1, y1, qp, ts, dep, bd, rg, smp, lm, dc)
+        dev.vvc355_dequant(P(b), lw, lh, x0, y0, x1, y1, qp, ts, dep, bd, rg, smp, lm, dc)
+        assert np.array_equal(a, b), f"dequant {1 << lw}x{1 << lh} rect=({x0},{y0})-({x1},{y1}) qp={qp} ts={ts} dep={dep} bd={bd} list={sm is not None} dc={dc}"
+        n += int(np.any(a != c))
+    assert n > 250
+
+
+def test_dequant_batch(dev, orc):
+    from ffvvc_amd import abi, batch
+    rng = np.random.default_rng(0x5EED0460)
+    cases = list(_dequant_cases(rng, 200))
+    arr = (abi.DequantJob * len(cases))()
+    bufs, want = [], []
+    for i, (lw, lh, x0, y0, x1, y1, qp, ts, dep, bd, rg, sm, lm, dc, c) in enumerate(cases):
+        a = c.copy()
+        orc.orc_dequant(P(a), lw, lh, x0, y0, x1, y1, qp, ts, dep, bd, rg, P(sm) if sm is not None else None, lm, dc)
+        want.append(a)
+        d_c = batch.DeviceBuffer.from_host(c)
+        d_m = batch.DeviceBuffer.from_host(sm) if sm is not None else None
+        bufs.append((d_c, d_m))
+        j = arr[i]
+        j.coeffs, j.scale_matrix = d_c.ptr, d_m.ptr if d_m else 0
+        j.log2_w, j.log2_h, j.min_x, j.min_y, j.max_x, j.max_y = lw, lh, x0, y0, x1, y1
+        j.qp, j.ts, j.dep_quant, j.bit_depth, j.range, j.log2_matrix_size, j.dc = qp, ts, dep, bd, rg, lm, dc
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_dequant_batch(None, d_jobs.ptr, len(cases))
+    dev.vvc355_stream_sync(None)
+    for (d_c, _), a in zip(bufs, want):
+        assert np.array_equal(d_c.to_host(np.int32, a.shape), a)

@@ -169,3 +169,69 @@ def test_avg_of_equal_predictions_is_identity(orc, bd):
     d = np.zeros((8, 16), px.dtype)
     orc.orc_avg(bd, P(d), 16 * d.itemsize, P(s), P(s), 16, 8)
     assert np.array_equal(d, px[:, :16])
+
+
+def test_dequant_closed_form(orc):
+    """8.7.3 with the flat matrix (m = 16) and levelScale[0][4] = 64: coeff * 64 * 16 * 2^(qp/6) >> bdShift.  For a square
+    8x8 block at 10-bit, range 15, no dependent quantisation, bdShift = 10 + 0 + 3 + 10 - 15 = 8, so qp = 4 + 6k is an
+    exact left shift by 2 + k (then the clip to 16 bits); transform skip uses bdShift = 10, i.e. a left shift by k."""
+    rng = np.random.default_rng(5)
+    c = rng.integers(-2000, 2000, size=(8, 8)).astype(np.int32)
+    for k in range(4):
+        a = c.copy()
+        orc.orc_dequant(P(a), 3, 3, 0, 0, 7, 7, 4 + 6 * k, 0, 0, 10, 15, None, 1, -1)
+        assert np.array_equal(a, np.clip(c << (2 + k), -(1 << 15), (1 << 15) - 1))
+        b = c.copy()
+        orc.orc_dequant(P(b), 3, 3, 0, 0, 7, 7, 4 + 6 * k, 1, 0, 10, 15, None, 1, -1)
+        assert np.array_equal(b, np.clip(c << k, -(1 << 15), (1 << 15) - 1))
+    # outside the scan rectangle nothing changes
+    a = c.copy()
+    orc.orc_dequant(P(a), 3, 3, 1, 2, 4, 5, 28, 0, 0, 10, 15, None, 1, -1)
+    keep = np.ones((8, 8), bool); keep[2:6, 1:5] = False
+    assert np.array_equal(a[keep], c[keep]) and np.any(a[~keep] != c[~keep])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_bipred_integer_motion_reads_clamped_samples(orc, bd):
+    """With whole-sample motion, no refinement and equal references, avg(put, put) gives back the reference samples; far
+    outside the picture that must be the replicated border (edge emulation, vvc_inter.c:33-110)."""
+    import ctypes
+    import bipred_cases as bc
+    from ffvvc_amd import abi
+    bc.bind_oracle(orc)
+    rng = np.random.default_rng(11)
+    pw, ph = 64, 48
+    ref = rand_pixels(rng, (ph, pw), bd)
+    for (x, y, mvx, mvy) in [(16, 16, 0, 0), (0, 0, -5 * 16, -3 * 16), (48, 32, 9 * 16, 40 * 16), (32, 0, -100 * 16, 7 * 16)]:
+        dst = np.zeros((16, 16), ref.dtype)
+        j = abi.BipredJob()
+        j.dst, j.ref0, j.ref1 = P(dst), P(ref), P(ref)
+        j.dst_stride, j.ref0_stride, j.ref1_stride = 16 * ref.itemsize, pw * ref.itemsize, pw * ref.itemsize
+        for k, v in enumerate((mvx, mvy, mvx, mvy)):
+            j.mv[k] = v
+        j.x, j.y, j.w, j.h, j.pic_w, j.pic_h = x, y, 16, 16, pw, ph
+        orc.orc_bipred_block(bd, ctypes.byref(j))
+        yy = np.clip(np.arange(16) + y + mvy // 16, 0, ph - 1)
+        xx = np.clip(np.arange(16) + x + mvx // 16, 0, pw - 1)
+        assert np.array_equal(dst, ref[yy][:, xx])
+
+
+def test_bipred_dmvr_early_termination(orc):
+    """Identical references with mirrored motion: the centre SAD is 0 < w*h, so there is no search, the motion stays and
+    the sub-block BDOF flag is cleared (vvc_inter.c:712, :744-746)."""
+    import ctypes
+    import bipred_cases as bc
+    from ffvvc_amd import abi
+    bc.bind_oracle(orc)
+    rng = np.random.default_rng(12)
+    ref = bc.smooth_picture(rng, 64, 64, 10)
+    dst = np.zeros((16, 16), ref.dtype)
+    rec = abi.BipredResult()
+    j = abi.BipredJob()
+    j.dst, j.ref0, j.ref1, j.rec = P(dst), P(ref), P(ref), ctypes.addressof(rec)
+    j.dst_stride, j.ref0_stride, j.ref1_stride = 32, 128, 128
+    for k, v in enumerate((37, -21, 37, -21)):
+        j.mv[k] = v
+    j.x, j.y, j.w, j.h, j.pic_w, j.pic_h, j.dmvr, j.bdof = 24, 24, 16, 16, 64, 64, 1, 1
+    orc.orc_bipred_block(10, ctypes.byref(j))
+    assert list(rec.mv) == [37, -21, 37, -21] and rec.searched == 0 and rec.bdof == 0 and rec.min_sad == 0
