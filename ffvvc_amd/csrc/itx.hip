@@ -524,40 +524,51 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
 }
 #undef ITX_SYNC
 
-// Scaling process for transform coefficients (vvc_intra.c:277-417): one workgroup per transform block, lanes over the scan
-// rectangle.  levelScale / qp arithmetic per derive_qp (:277) and derive_scale (:311).
-__global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *__restrict__ jobs)
+// Scaling process for transform coefficients (vvc_intra.c:277-417): 16 lanes per transform block (most blocks are small and
+// their non-zero windows smaller still), lanes over the scan rectangle.  levelScale / qp arithmetic per derive_qp (:277) and
+// derive_scale (:311).
+__global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *__restrict__ jobs, int n_jobs)
 {
-    const vvc355_dequant_job job = jobs[blockIdx.x];
+    const int ji = blockIdx.x * 16 + (threadIdx.x >> 4), tid = threadIdx.x & 15;
+    if (ji >= n_jobs)
+        return;
+    const vvc355_dequant_job job = jobs[ji];
     const int lw = job.log2_w, lh = job.log2_h, log_sum = lw + lh;
     const int rect = job.ts ? 0 : (log_sum & 1);
     const int bd_shift = job.ts ? 10 : job.bit_depth + rect + (log_sum / 2) + 10 - job.range + job.dep_quant;
     const int bd_offset = (1 << bd_shift) >> 1;
     const int qp = job.qp + (job.dep_quant && !job.ts ? 1 : 0);
-    const int ls0[6] = { 40, 45, 51, 57, 64, 72 }, ls1[6] = { 57, 64, 72, 80, 90, 102 };
     const int rem = qp % 6;
-    int lsv = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) if (k == rem) lsv = rect ? ls1[k] : ls0[k];
+    // levelScale[rect][rem]: { 40, 45, 51, 57, 64, 72 } / { 57, 64, 72, 80, 90, 102 }
+    const int lsv = rect ? (rem == 0 ? 57 : rem == 1 ? 64 : rem == 2 ? 72 : rem == 3 ? 80 : rem == 4 ? 90 : 102)
+                         : (rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72);
     const int scale = lsv << (qp / 6);
     const int rw = job.max_x - job.min_x + 1, rh = job.max_y - job.min_y + 1;
     int *coeffs = (int *)job.coeffs;
     const uint8_t *sm = (const uint8_t *)job.scale_matrix;
     const int lm = job.log2_matrix_size;
-    for (int i = threadIdx.x; i < rw * rh; i += 256) {
-        const int y = job.min_y + i / rw, x = job.min_x + i % rw;
-        const int c = gld<int>(coeffs + (y << lw) + x);
-        if (!c)
+    // lane -> column (tid mod rw') with rw' = rw rounded up to a power of two <= 16, so that no division is needed per element
+    const int cw = rw >= 16 ? 16 : rw > 8 ? 16 : rw > 4 ? 8 : rw > 2 ? 4 : rw > 1 ? 2 : 1;    // columns per pass
+    const int rows_per_pass = 16 / cw;
+    for (int xb = 0; xb < rw; xb += 16) {
+        const int xo = xb + (tid & (cw - 1));
+        if (xo >= rw)
             continue;
-        int m = 16;
-        if (sm) {
-            // derive_scale_m :373-381: nearest-neighbour up-sampling of the recorded matrix, DC override at the origin
-            m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
-            if (job.dc >= 0 && i == 0 && job.min_x == 0 && job.min_y == 0)
-                m = job.dc;
+        for (int yo = tid / cw; yo < rh; yo += rows_per_pass) {
+            const int y = job.min_y + yo, x = job.min_x + xo;
+            const int c = gld<int>(coeffs + (y << lw) + x);
+            if (!c)
+                continue;
+            int m = 16;
+            if (sm) {
+                // derive_scale_m :373-381: nearest-neighbour up-sampling of the recorded matrix, DC override at the origin
+                m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
+                if (job.dc >= 0 && x == 0 && y == 0)
+                    m = job.dc;
+            }
+            const int v = (int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift;
+            gst<int>(coeffs + (y << lw) + x, clip_intp2(v, job.range));
         }
-        const int v = (int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift;
-        gst<int>(coeffs + (y << lw) + x, clip_intp2(v, job.range));
     }
 }
 
@@ -686,7 +697,7 @@ void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev
 void vvc355_dequant_batch(void *stream, const vvc355_dequant_job *jobs_dev, int n_jobs)
 {
     if (n_jobs <= 0) return;
-    hipLaunchKernelGGL(dequant_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    hipLaunchKernelGGL(dequant_kernel, dim3((n_jobs + 15) / 16), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
     HIP_CHECK(hipGetLastError());
 }
 

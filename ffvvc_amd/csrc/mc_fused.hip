@@ -306,7 +306,9 @@ struct BipredLds {
     int16_t smp[2][kGs * kGs];
     union {
         int16_t grad[4][kGs * kGs];      // gh0, gh1, gv0, gv1
-        int16_t bil[2][kBilP * kBilP];   // DMVR search planes (dead before the gradients are written)
+        int16_t bil[2][2][kBilP * kBilP + 4];   // DMVR search planes [ref][natural | shifted by one sample] (dead before the
+                                                 // gradients are written); the shifted copy keeps sample pairs 4-byte aligned
+                                                 // for odd search offsets
     };
     int sad[28];
 };
@@ -353,68 +355,108 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
         store_rows<11>(L.win[1], lane, r1);
         wave_sync();
     }
-    // inter.dmvr[!!my][!!mx] (vvc_inter_template.c:324-413): lane -> column lane & 31, rows (lane >> 5) + 2 it
+    // inter.dmvr[!!my][!!mx] (vvc_inter_template.c:324-413).  Lane -> (reference, pair of adjacent columns, segment of rows):
+    // the horizontal stage of two outputs is two packed dot products on aligned sample pairs, and walking down the rows lets
+    // the vertical stage reuse the previous row's horizontal result.
     const int sh1 = BD - 6, off1 = 1 << (sh1 - 1);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int mx = mv[2 * i] & 15, my = mv[2 * i + 1] & 15;
-        const uint16_t *win = L.win[i];
-        const int x = lane & 31;
-        if (x < pw) {
-            for (int r = lane >> 5; r < ph; r += 2) {
-                const int a = win[r * kWinW + x], b = win[r * kWinW + x + 1];
-                const int c = win[(r + 1) * kWinW + x], d = win[(r + 1) * kWinW + x + 1];
-                int v;
-                if (mx && my) {
-                    const int t0 = (int16_t)(((16 - mx) * a + mx * b + off1) >> sh1);
-                    const int t1 = (int16_t)(((16 - mx) * c + mx * d + off1) >> sh1);
-                    v = ((16 - my) * t0 + my * t1 + 8) >> 4;
-                } else if (mx) {
-                    v = ((16 - mx) * a + mx * b + off1) >> sh1;
-                } else if (my) {
-                    v = ((16 - my) * a + my * c + off1) >> sh1;
-                } else if (BD > 10) {
-                    v = (a + (1 << (BD - 11))) >> (BD - 10);
+    {
+        const int npair = pw >> 1;                                   // 6 or 10
+        const int nseg = npair == 10 ? 3 : 5;                        // 2 * npair * nseg <= 64
+        const int rps = (ph + nseg - 1) / nseg;                      // rows per segment
+        const int per_ref = npair * nseg;
+        const int i = lane >= per_ref, id = lane - i * per_ref;
+        const int seg = npair == 10 ? (id >= 20 ? 2 : id >= 10 ? 1 : 0) : (id >= 24 ? 4 : id >= 18 ? 3 : id >= 12 ? 2 : id >= 6 ? 1 : 0);
+        const int cp = id - seg * npair;
+        if (lane < 2 * per_ref) {
+            const int mx = mv[2 * i] & 15, my = mv[2 * i + 1] & 15;
+            const uint32_t hc = pack16(16 - mx, mx);
+            const uint16_t *win = L.win[i] + 2 * cp;
+            const int r0 = seg * rps, r1 = min(r0 + rps, ph);
+            // horizontal stage of row r for the two columns
+            auto hstage = [&](int r, int &t0, int &t1) {
+                const uint32_t p0 = *(const uint32_t *)(win + r * kWinW), p1 = *(const uint32_t *)(win + r * kWinW + 2);
+                if (mx) {
+                    t0 = (dot2(p0, hc, 0) + off1) >> sh1;
+                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, 0) + off1) >> sh1;
+                    if (my) { t0 = (int16_t)t0; t1 = (int16_t)t1; }
                 } else {
-                    v = a << (10 - BD);
+                    t0 = p0 & 0xffff; t1 = p0 >> 16;
                 }
-                L.bil[i][r * kBilP + x] = (int16_t)v;
+            };
+            int a0, a1;
+            hstage(r0, a0, a1);
+            for (int r = r0; r < r1; r++) {
+                int v0, v1, b0 = 0, b1 = 0;
+                if (my)
+                    hstage(r + 1, b0, b1);
+                if (mx && my)      { v0 = ((16 - my) * a0 + my * b0 + 8) >> 4;         v1 = ((16 - my) * a1 + my * b1 + 8) >> 4; }
+                else if (mx)       { v0 = a0;                                           v1 = a1; }
+                else if (my)       { v0 = ((16 - my) * a0 + my * b0 + off1) >> sh1;     v1 = ((16 - my) * a1 + my * b1 + off1) >> sh1; }
+                else if (BD > 10)  { v0 = (a0 + (1 << (BD - 11))) >> (BD - 10);         v1 = (a1 + (1 << (BD - 11))) >> (BD - 10); }
+                else               { v0 = a0 << (10 - BD);                              v1 = a1 << (10 - BD); }
+                const int e = r * kBilP + 2 * cp;
+                *(uint32_t *)&L.bil[i][0][e] = pack16(v0, v1);
+                // shifted copy: element j holds natural element j + 1 (slot -1 of row 0 lands in the 4 spare elements)
+                L.bil[i][1][e + 3] = (int16_t)v0;
+                L.bil[i][1][e + 4] = (int16_t)v1;
+                if (my) { a0 = b0; a1 = b1; }
+                else if (r + 1 < r1) hstage(r + 1, a0, a1);
             }
         }
     }
     wave_sync();
-    // inter.sad (vvcdsp.c:49): every other row; lane -> column lane & 15, row pairs (lane >> 4) + 4 k
-    const int sx = lane & 15, sr = lane >> 4;
-    auto sad_at = [&](int dx, int dy) {
-        const int16_t *a = L.bil[0] + (dy) * kBilP + dx;                   // (2 + (dy - 2)), (2 + (dx - 2))
-        const int16_t *b = L.bil[1] + (4 - dy) * kBilP + (4 - dx);
+    // inter.sad (vvcdsp.c:49): every other row.  plane(i, par) + n addresses natural element n of reference i through the copy
+    // in which an offset of parity `par` is 4-byte aligned.
+    auto plane = [&](int i, int par) { return par ? L.bil[i][1] + 4 - 1 : L.bil[i][0]; };
+    int min_sad;
+    {
+        // centre cost over the whole wave: lane -> (pair of columns lane & 7, row pair lane >> 3)
+        const int xp = lane & 7, r = lane >> 3;
         int acc = 0;
-        if (sx < w)
-            for (int r = sr; 2 * r < h; r += 4)
-                acc += abs((int)a[2 * r * kBilP + sx] - (int)b[2 * r * kBilP + sx]);
-        return wave_sum(acc);
-    };
-    int min_sad = sad_at(2, 2);
+        if (2 * xp < w && 2 * r < h) {
+            const uint32_t a = *(const uint32_t *)(L.bil[0][0] + (2 + 2 * r) * kBilP + 2 + 2 * xp);
+            const uint32_t b = *(const uint32_t *)(L.bil[1][0] + (2 + 2 * r) * kBilP + 2 + 2 * xp);
+            acc = __builtin_amdgcn_sad_u16(a, b, 0);
+        }
+        min_sad = wave_sum(acc);
+    }
     min_sad -= min_sad >> 2;
     int min_dx = 2, min_dy = 2;
     searched = 0;
     if (min_sad >= w * h) {
         searched = 1;
-        if (lane == 0)
-            L.sad[12] = min_sad;
-        // 8.5.3.4 array entry selection, scan order dy outer / dx inner, first minimum wins
-        for (int k = 0; k < 25; k++) {
-            if (k == 12)
-                continue;
-            const int dy = k / 5, dx = k - dy * 5;
-            const int s = sad_at(dx, dy);
-            if (lane == 0)
-                L.sad[k] = s;
-            if (s < min_sad) {
-                min_sad = s;
-                min_dx = dx;
-                min_dy = dy;
+        // the 25 costs without wave-wide reductions: lanes 2k and 2k + 1 own offset k and sum alternate row pairs
+        {
+            const int k = lane >> 1, half = lane & 1;
+            uint32_t acc = 0;
+            if (k < 25) {
+                const int dy = k / 5, dx = k - dy * 5;
+                const int16_t *a = plane(0, dx & 1) + dy * kBilP + dx;
+                const int16_t *b = plane(1, dx & 1) + (4 - dy) * kBilP + (4 - dx);
+                for (int r = half; 2 * r < h; r += 2) {
+                    const uint32_t *ar = (const uint32_t *)(a + 2 * r * kBilP), *br = (const uint32_t *)(b + 2 * r * kBilP);
+                    for (int x = 0; 2 * x < w; x++)
+                        acc = __builtin_amdgcn_sad_u16(ar[x], br[x], acc);
+                }
             }
+            acc += __shfl_xor(acc, 1, 64);
+            if (k < 25 && !half)
+                L.sad[k] = k == 12 ? min_sad : (int)acc;
+        }
+        wave_sync();
+        // 8.5.3.4 array entry selection: the centre wins ties, then the earliest offset in scan order (dy outer, dx inner) =
+        // the minimum of (cost, priority) pairs
+        {
+            uint32_t key = 0xffffffffu;
+            if (lane < 25)
+                key = ((uint32_t)L.sad[lane] << 5) | (uint32_t)(lane == 12 ? 0 : lane + 1);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+                key = min(key, (uint32_t)__shfl_xor((int)key, m, 64));
+            min_sad = (int)(key >> 5);
+            const int kk = key & 31, k = kk ? kk - 1 : 12;
+            min_dy = k / 5;
+            min_dx = k - min_dy * 5;
         }
         wave_sync();
         int dmv0 = (min_dx - 2) * 16, dmv1 = (min_dy - 2) * 16;
@@ -503,40 +545,51 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
         smp1[t] = smp1[t + kGs]; smp1[b] = smp1[b - kGs];
     }
     wave_sync();
-    // 16 lanes per 4x4 sub-block, four sub-blocks per pass (derive_bdof_vx_vy :237, apply_bdof_min_block :267)
-    const int sbw = w >> 2, nsb = sbw * (h >> 2), l = lane & 15;
-    uint8_t *dst = (uint8_t *)job->dst;
-    for (int sb = lane >> 4; sb < nsb; sb += 4) {
-        const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
-        int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
-        for (int e = l; e < 36; e += 16) {
-            const int j = e / 6, i = e - j * 6;
-            const int o = (by + j) * kGs + bx + i;
-            const int diff = (smp0[o] >> 4) - (smp1[o] >> 4);
-            const int th = (gh0[o] + gh1[o]) >> 1;
-            const int tv = (gv0[o] + gv1[o]) >> 1;
-            sgx2 += abs(th);
-            sgy2 += abs(tv);
-            sgxgy += sign_of(tv) * th;
-            sgxdi += -sign_of(th) * diff;
-            sgydi += -sign_of(tv) * diff;
-        }
+    // four lanes per 4x4 sub-block, all (at most 16) sub-blocks at once (derive_bdof_vx_vy :237, apply_bdof_min_block :267):
+    // a lane sums 9 of the 36 window positions, two quad exchanges finish the sums, then it writes one row of the sub-block
+    const int sbw = w >> 2, nsb = sbw * (h >> 2);
+    const int sb = lane >> 2, q = lane & 3;
+    if (sb >= nsb)
+        return;                                          // whole quads leave together
+    const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
+    int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
 #pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) {
-            sgx2 += __shfl_xor(sgx2, m, 16);
-            sgy2 += __shfl_xor(sgy2, m, 16);
-            sgxgy += __shfl_xor(sgxgy, m, 16);
-            sgxdi += __shfl_xor(sgxdi, m, 16);
-            sgydi += __shfl_xor(sgydi, m, 16);
-        }
-        const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;
-        const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
-        const int py = by + (l >> 2), px = bx + (l & 3);
-        const int o = (py + 1) * kGs + px + 1;
-        const int sh = 15 - BD, off = 1 << (sh - 1);
-        const int corr = vx * (gh0[o] - gh1[o]) + vy * (gv0[o] - gv1[o]);
-        st_px<BD>(dst + (ptrdiff_t)py * job->dst_stride, px, clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh));
+    for (int t = 0; t < 9; t++) {
+        const int e = q + 4 * t, j = e / 6, i = e - j * 6;
+        const int o = (by + j) * kGs + bx + i;
+        const int diff = (smp0[o] >> 4) - (smp1[o] >> 4);
+        const int th = (gh0[o] + gh1[o]) >> 1;
+        const int tv = (gv0[o] + gv1[o]) >> 1;
+        sgx2 += abs(th);
+        sgy2 += abs(tv);
+        sgxgy += sign_of(tv) * th;
+        sgxdi += -sign_of(th) * diff;
+        sgydi += -sign_of(tv) * diff;
     }
+#pragma unroll
+    for (int m = 2; m >= 1; m >>= 1) {
+        sgx2 += __shfl_xor(sgx2, m, 4);
+        sgy2 += __shfl_xor(sgy2, m, 4);
+        sgxgy += __shfl_xor(sgxgy, m, 4);
+        sgxdi += __shfl_xor(sgxdi, m, 4);
+        sgydi += __shfl_xor(sgydi, m, 4);
+    }
+    const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;
+    const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
+    const int sh = 15 - BD, off = 1 << (sh - 1);
+    const int py = by + q;
+    uint8_t *drow = (uint8_t *)job->dst + (ptrdiff_t)py * job->dst_stride;
+    int out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int o = (py + 1) * kGs + bx + k + 1;
+        const int corr = vx * (gh0[o] - gh1[o]) + vy * (gv0[o] - gv1[o]);
+        out[k] = clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh);
+    }
+    if (BD > 8)
+        gst<uint2>(drow + bx * 2, make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16)));
+    else
+        gst<uint32_t>(drow + bx, (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24));
 }
 
 // both references at motion mv: windows through clamped coordinates, then the separable interpolation of interp_block
