@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CTB = 128
 # what the chain still lacks of BASELINE.json configs[3] (8K random-access, full in-loop filter chain)
@@ -139,7 +140,7 @@ def build_chain(lib, torch, fr):
         j["x"], j["y"], j["w"], j["h"] = x0 >> sh, y0 >> sh, bs >> sh, bs >> sh
         j["pic_w"], j["pic_h"] = w, h
         j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
-        j["dmvr"], j["bdof"] = 1, 1
+        j["dmvr"], j["bdof"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
         bj.append(j)
     luma_jobs, chroma_jobs = bj[0], np.concatenate(bj[1:])
     d_bl, d_bc = fr.upload(luma_jobs.view(np.uint8)), fr.upload(chroma_jobs.view(np.uint8))
@@ -148,7 +149,7 @@ def build_chain(lib, torch, fr):
 
     def launch_bipred(st):
         lib.vvc355_bipred_batch(st, bd, ptr(d_bl), n_bl)          # luma: refines the motion, writes the records
-        lib.vvc355_bipred_batch(st, bd, ptr(d_bc), n_bc)          # chroma of both planes at the refined motion
+        lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc)   # chroma of both planes at the refined motion
 
     chain.append(Stage("inter_pred_bi_dmvr_bdof", f"bipred_kernel<{bd}>", launch_bipred,
                        inter_samples * 3 * isz))            # two reference samples read + one sample written
@@ -486,12 +487,15 @@ def parse_args():
     ap.add_argument("--bd", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
+    ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
+    global MC_TOOLS
+    MC_TOOLS = args.mc_tools & 3
     import torch
     import torch.distributed as dist
 
@@ -567,7 +571,7 @@ def main():
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
                             f"(80 % bi-pred inter CTUs, 20 % intra), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING,
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only else ["PROFILING RUN: --mc-tools / --only reduce the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {

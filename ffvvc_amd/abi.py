@@ -110,6 +110,7 @@ BATCH_SIGNATURES = {
     "cclm_batch":       ("v", "pipi"),
     "pred_fused_batch": ("v", "pipi"),
     "bipred_batch":     ("v", "pipi"),
+    "bipred_chroma_batch": ("v", "pipi"),
 }
 
 

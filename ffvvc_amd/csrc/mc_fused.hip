@@ -13,6 +13,7 @@
 // horizontally adjacent outputs per step from aligned sample pairs with v_dot2c_i32_i16 (9 dot products for two 8-tap
 // outputs, 5 for two 4-tap outputs) and writes the intermediate transposed, so that the vertical pass again reads aligned
 // pairs.  The kernel is VALU-issue bound (rocprofv3: > 80 % of the per-SIMD VALU slots), hence the 4-tap specialisation.
+#include <type_traits>
 #include "common.hpp"
 #include "runtime.hpp"
 #include "../../include/vvc_mi355.h"
@@ -300,15 +301,22 @@ __device__ __forceinline__ int wave_sum(int v)
 static constexpr int kBilP = 20;        // DMVR bilinear plane pitch: (16 + 4) columns
 static constexpr int kGs = 18;          // BDOF planes: block + one-sample ring
 
+// Per-wave LDS, overlaid by phase: DMVR = win + bil, interpolation = win + tmpT, BDOF = smp + grad (each phase ends with a
+// wave barrier before the next one writes).  5.5 KB per wave keeps 28 waves on a CU.
 struct BipredLds {
-    uint16_t win[2][kWinH * kWinW];
-    int16_t tmpT[16 * kTmpP];
-    int16_t smp[2][kGs * kGs];
     union {
-        int16_t grad[4][kGs * kGs];      // gh0, gh1, gv0, gv1
-        int16_t bil[2][2][kBilP * kBilP + 4];   // DMVR search planes [ref][natural | shifted by one sample] (dead before the
-                                                 // gradients are written); the shifted copy keeps sample pairs 4-byte aligned
-                                                 // for odd search offsets
+        struct {
+            uint16_t win[2][kWinH * kWinW];
+            union {
+                int16_t tmpT[16 * kTmpP];
+                int16_t bil[2][2][kBilP * kBilP + 4];   // DMVR search planes [ref][natural | shifted by one sample]; the shifted
+                                                         // copy keeps sample pairs 4-byte aligned for odd search offsets
+            };
+        };
+        struct {
+            int16_t smp[2][kGs * kGs];
+            int16_t grad[4][kGs * kGs];                  // gh0, gh1, gv0, gv1
+        };
     };
     int sad[28];
 };
@@ -623,26 +631,34 @@ __device__ __forceinline__ void predict_clamped(const vvc355_bipred_job *job, Bi
     interp_block<BD, NTAP>(lw, h, fx[1] != 0, fy[1] != 0, t[1][0], t[1][1], t[1][2], t[1][3], L.win[1], L.tmpT, lane, v1);
 }
 
-template <int BD>
+// the window / intermediate part of BipredLds only: what a launch of chroma jobs needs (more waves per CU)
+struct BipredLdsLight {
+    uint16_t win[2][kWinH * kWinW];
+    int16_t tmpT[16 * kTmpP];
+};
+
+template <int BD, bool TOOLS>
 __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
 {
-    __shared__ __attribute__((aligned(16))) BipredLds lds_all[4];
+    __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLds, BipredLdsLight>::type lds_all[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ji = blockIdx.x * 4 + wave;
     if (ji >= n_jobs)
         return;
     const vvc355_bipred_job *job = jobs + ji;            // wave-uniform
-    BipredLds &L = lds_all[wave];
+    BipredLds &L = *(BipredLds *)&lds_all[wave];      // without TOOLS only win / tmpT are touched
+    if (!TOOLS && !job->chroma)
+        return;                                          // contract: a chroma-only launch holds chroma jobs
     const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr;
     const int lw = 31 - __builtin_clz(w);
     vvc355_bipred_result *rec = (vvc355_bipred_result *)job->rec;
     int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
-    int bdof = !chroma && job->bdof;
+    int bdof = TOOLS && !chroma && job->bdof;
     if (chroma && rec) {
 #pragma unroll
         for (int k = 0; k < 4; k++) mv[k] = gld<int>(&rec->mv[k]);
     }
-    if (!chroma) {
+    if (TOOLS && !chroma) {
         int min_sad = 0, searched = 0;
         if (dmvr)
             dmvr_refine<BD>(job, L, lane, mv, bdof, min_sad, searched);
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
         predict_clamped<BD, 8>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1);
 #pragma unroll
     for (int i = 0; i < 4; i++) { v0[i] = (int16_t)v0[i]; v1[i] = (int16_t)v1[i]; }     // put[..] stores int16
-    if (bdof) {
+    if (TOOLS && bdof) {
         bdof_wave<BD>(job, L, lane, w, h, v0, v1, ox, oy, fx, fy, rc);
         return;
     }
@@ -716,6 +732,14 @@ extern "C" void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_jo
 {
     using namespace vvc355;
     if (n_jobs <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD, true>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs)
+{
+    using namespace vvc355;
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD, false>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
     HIP_CHECK(hipGetLastError());
 }

@@ -429,6 +429,8 @@ typedef struct vvc355_bipred_result {
 } vvc355_bipred_result;
 
 void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs);
+/* the same for a launch in which EVERY job has chroma != 0 (jobs that do not are skipped): smaller LDS footprint */
+void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs);
 
 #ifdef __cplusplus
 }

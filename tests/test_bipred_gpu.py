@@ -93,7 +93,7 @@ def test_bipred_frame(dev, orc, bd):
             chroma[nc] = dj; nc += 1
     d_l, d_c = batch.jobs_to_device(luma), batch.jobs_to_device(chroma)
     dev.vvc355_bipred_batch(None, bd, d_l.ptr, nl)
-    dev.vvc355_bipred_batch(None, bd, d_c.ptr, nc)
+    (dev.vvc355_bipred_chroma_batch if bd != 8 else dev.vvc355_bipred_batch)(None, bd, d_c.ptr, nc)     # both entries
     dev.vvc355_stream_sync(None)
 
     got_rec = d_rec.to_host(np.int32, (n, 8))
