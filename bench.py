@@ -221,29 +221,22 @@ def build_chain(lib, torch, fr):
     fr.keep.append(coeffs)
     itx_all = np.concatenate(tj)
     itx_all["coeffs"] += coeffs.data_ptr()
-    d_itx = fr.upload(itx_all.view(np.uint8))
     n_itx = len(itx_all)
     n_samples = coeff_off // 4
     jsz = itx_all.dtype.itemsize
 
-    # scaling process (dequant) of every transform block over the window that holds non-zero levels: flat scaling matrix,
-    # qp 22..37, dependent quantisation on for half of the blocks (vvc_intra.c:277-417)
-    dq = batch.job_array(abi.DequantJob, n_itx)
-    dq["coeffs"] = itx_all["coeffs"]
-    dq["log2_w"], dq["log2_h"] = itx_all["log2_w"], itx_all["log2_h"]
-    dq["max_x"], dq["max_y"] = itx_all["nzw"] - 1, itx_all["nzh"] - 1
-    dq["qp"] = rng.integers(22, 38, size=n_itx)
-    dq["dep_quant"] = rng.integers(0, 2, size=n_itx)
-    dq["bit_depth"], dq["range"], dq["log2_matrix_size"], dq["dc"] = bd, 15, 1, -1
-    d_dq = fr.upload(dq.view(np.uint8))
-    window = int(np.sum(itx_all["nzw"].astype(np.int64) * itx_all["nzh"].astype(np.int64)))
-    chain.append(Stage("dequant", "dequant_kernel", lambda st: lib.vvc355_dequant_batch(st, ptr(d_dq), n_itx), window * 8))
+    # the scaling process (dequant, vvc_intra.c:277-417) is fused into the transform's load stage: flat scaling matrix,
+    # qp 22..37, dependent quantisation on for half of the blocks
+    itx_all["dq_flags"] = 1 | (rng.integers(0, 2, size=n_itx) << 1)
+    itx_all["dq_qp"] = rng.integers(22, 38, size=n_itx)
+    itx_all["log2_matrix_size"], itx_all["dc"] = 1, -1
+    d_itx = fr.upload(itx_all.view(np.uint8))
 
     def launch_itx(st):
         for (first, count, lg) in itx_launches:
             lib.vvc355_itx_shape_batch(st, bd, ptr(d_itx) + first * jsz, count, lg, lg)
 
-    chain.append(Stage("itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz)))
+    chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz)))
 
     # ---------------------------------------------------------------- LMCS inverse luma mapping
     lut = fr.upload(np.sort(rng.integers(0, 1 << bd, size=1 << bd)).astype(np.uint8 if bd == 8 else np.uint16))

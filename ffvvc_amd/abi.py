@@ -207,7 +207,8 @@ class ItxJob(ctypes.Structure):
         ("coeffs", ctypes.c_uint64), ("dst", ctypes.c_uint64), ("dst_stride", ctypes.c_int32),
         ("trh", ctypes.c_uint8), ("trv", ctypes.c_uint8), ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8),
         ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8), ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8),
-        ("store_coeffs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 3),
+        ("store_coeffs", ctypes.c_uint8), ("dq_flags", ctypes.c_uint8), ("dq_qp", ctypes.c_uint8), ("log2_matrix_size", ctypes.c_uint8),
+        ("scale_matrix", ctypes.c_uint64), ("dc", ctypes.c_int16), ("pad_", ctypes.c_uint8 * 6),
     ]
 
 

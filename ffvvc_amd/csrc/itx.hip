@@ -56,6 +56,47 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
     return (int)acc;
 }
 
+// Scaling process for transform coefficients (vvc_intra.c:277-417) as a per-coefficient function: derive_qp's shift and
+// rectangular correction (:297-309), derive_scale (:311-338), derive_scale_m's up-sampling and DC override (:373-381),
+// scale_coeff (:391-397).  Shared by dequant_kernel and by the itx kernels' fused load stage.
+struct Dequant {
+    int on, scale, bd_shift, bd_offset, range, lw, lh, lm, dc;
+    const uint8_t *sm;
+    __device__ __forceinline__ void setup(int enable, int lw_, int lh_, int qp_in, int ts, int dep_quant, int bit_depth, int range_,
+                                          const uint8_t *sm_, int lm_, int dc_)
+    {
+        on = enable; lw = lw_; lh = lh_; range = range_; sm = sm_; lm = lm_; dc = dc_;
+        const int log_sum = lw + lh, rect = ts ? 0 : (log_sum & 1);
+        bd_shift = ts ? 10 : bit_depth + rect + (log_sum / 2) + 10 - range + dep_quant;
+        bd_offset = (1 << bd_shift) >> 1;
+        const int qp = qp_in + (dep_quant && !ts ? 1 : 0), rem = qp % 6;
+        // levelScale[rect][rem]: { 40, 45, 51, 57, 64, 72 } / { 57, 64, 72, 80, 90, 102 }
+        const int lsv = rect ? (rem == 0 ? 57 : rem == 1 ? 64 : rem == 2 ? 72 : rem == 3 ? 80 : rem == 4 ? 90 : 102)
+                             : (rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72);
+        scale = lsv << (qp / 6);
+    }
+    __device__ __forceinline__ int apply(int c, int x, int y) const
+    {
+        if (!on || !c)
+            return c;
+        int m = 16;
+        if (sm) {
+            m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
+            if (dc >= 0 && x == 0 && y == 0)
+                m = dc;
+        }
+        return clip_intp2((int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift, range);
+    }
+};
+
+__device__ __forceinline__ Dequant itx_job_dequant(const vvc355_itx_job &job, int bd)
+{
+    Dequant dq;
+    dq.setup(job.dq_flags & 1, job.log2_w, job.log2_h, job.dq_qp, 0, (job.dq_flags >> 1) & 1, bd, job.range,
+             (const uint8_t *)job.scale_matrix, job.log2_matrix_size, job.dc);
+    return dq;
+}
+
 #define ITX_SYNC()                                                                  \
     do {                                                                            \
         if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
@@ -95,17 +136,24 @@ __device__ __forceinline__ void itx_generic_block(const vvc355_itx_job &job, int
             }
         }
     }
+    const Dequant dq = itx_job_dequant(job, bd);
     if (PER < 4) {
 #pragma unroll
         for (int q = 0; q < PER; q++)
             if (e0 + q < n)
-                buf[e0 + q] = gld<int>(coeffs + e0 + q);
+                buf[e0 + q] = dq.apply(gld<int>(coeffs + e0 + q), (e0 + q) & (w - 1), (e0 + q) >> job.log2_w);
     } else {
 #pragma unroll
         for (int c4 = 0; c4 < PER / 4; c4++) {
             const int e = e0 + c4 * 4;
-            if (e < n)                               // n is a multiple of 4 for every block of >= 4 coefficients
-                *(int4 *)&buf[e] = gld<int4>(coeffs + e);
+            if (e < n) {                             // n is a multiple of 4 for every block of >= 4 coefficients
+                int4 v = gld<int4>(coeffs + e);
+                if (dq.on) {
+                    const int y = e >> job.log2_w, x = e & (w - 1);      // w >= 4 here: the four share a row
+                    v.x = dq.apply(v.x, x, y); v.y = dq.apply(v.y, x + 1, y); v.z = dq.apply(v.z, x + 2, y); v.w = dq.apply(v.w, x + 3, y);
+                }
+                *(int4 *)&buf[e] = v;
+            }
         }
     }
     ITX_SYNC();
@@ -397,6 +445,7 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
         }
     }
     int c[4][4];
+    const Dequant dq = itx_job_dequant(job, bd);
     const bool need = act && y0 < cntv && x0 < nzw && x0 < KVH;
     unsigned mag = 0;
 #pragma unroll
@@ -404,6 +453,10 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
         int4 v = make_int4(0, 0, 0, 0);
         if (need && y0 + r < cntv)
             v = gld<int4>(coeffs + (y0 + r) * W + x0);
+        if (dq.on) {
+            v.x = dq.apply(v.x, x0, y0 + r); v.y = dq.apply(v.y, x0 + 1, y0 + r);
+            v.z = dq.apply(v.z, x0 + 2, y0 + r); v.w = dq.apply(v.w, x0 + 3, y0 + r);
+        }
         c[r][0] = x0 + 0 < nzw ? v.x : 0; c[r][1] = x0 + 1 < nzw ? v.y : 0;
         c[r][2] = x0 + 2 < nzw ? v.z : 0; c[r][3] = x0 + 3 < nzw ? v.w : 0;
 #pragma unroll
@@ -533,20 +586,12 @@ __global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *
     if (ji >= n_jobs)
         return;
     const vvc355_dequant_job job = jobs[ji];
-    const int lw = job.log2_w, lh = job.log2_h, log_sum = lw + lh;
-    const int rect = job.ts ? 0 : (log_sum & 1);
-    const int bd_shift = job.ts ? 10 : job.bit_depth + rect + (log_sum / 2) + 10 - job.range + job.dep_quant;
-    const int bd_offset = (1 << bd_shift) >> 1;
-    const int qp = job.qp + (job.dep_quant && !job.ts ? 1 : 0);
-    const int rem = qp % 6;
-    // levelScale[rect][rem]: { 40, 45, 51, 57, 64, 72 } / { 57, 64, 72, 80, 90, 102 }
-    const int lsv = rect ? (rem == 0 ? 57 : rem == 1 ? 64 : rem == 2 ? 72 : rem == 3 ? 80 : rem == 4 ? 90 : 102)
-                         : (rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72);
-    const int scale = lsv << (qp / 6);
+    const int lw = job.log2_w;
+    Dequant dq;
+    dq.setup(1, lw, job.log2_h, job.qp, job.ts, job.dep_quant, job.bit_depth, job.range, (const uint8_t *)job.scale_matrix,
+             job.log2_matrix_size, job.dc);
     const int rw = job.max_x - job.min_x + 1, rh = job.max_y - job.min_y + 1;
     int *coeffs = (int *)job.coeffs;
-    const uint8_t *sm = (const uint8_t *)job.scale_matrix;
-    const int lm = job.log2_matrix_size;
     // lane -> column (tid mod rw') with rw' = rw rounded up to a power of two <= 16, so that no division is needed per element
     const int cw = rw >= 16 ? 16 : rw > 8 ? 16 : rw > 4 ? 8 : rw > 2 ? 4 : rw > 1 ? 2 : 1;    // columns per pass
     const int rows_per_pass = 16 / cw;
@@ -557,17 +602,8 @@ __global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *
         for (int yo = tid / cw; yo < rh; yo += rows_per_pass) {
             const int y = job.min_y + yo, x = job.min_x + xo;
             const int c = gld<int>(coeffs + (y << lw) + x);
-            if (!c)
-                continue;
-            int m = 16;
-            if (sm) {
-                // derive_scale_m :373-381: nearest-neighbour up-sampling of the recorded matrix, DC override at the origin
-                m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
-                if (job.dc >= 0 && x == 0 && y == 0)
-                    m = job.dc;
-            }
-            const int v = (int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift;
-            gst<int>(coeffs + (y << lw) + x, clip_intp2(v, job.range));
+            if (c)
+                gst<int>(coeffs + (y << lw) + x, dq.apply(c, x, y));
         }
     }
 }

@@ -241,7 +241,15 @@ typedef struct vvc355_itx_job {
     uint64_t dst;
     int32_t  dst_stride;
     uint8_t  trh, trv, log2_w, log2_h, nzw, nzh, range, bd;
-    uint8_t  store_coeffs, pad_[3];
+    uint8_t  store_coeffs;
+    /* optional fused scaling process (dequant, vvc_intra.c:277-417) applied to the levels as they are loaded, for blocks
+     * that go straight from dequant to the transform (no LFNST, no transform skip): dq_flags bit 0 = on, bit 1 =
+     * sh_dep_quant_used_flag; dq_qp = tb->qp; scale_matrix / log2_matrix_size / dc as in vvc355_dequant_job below.
+     * Levels outside [0, nzw) x [0, nzh) must be zero (they are: the window holds every coded level). */
+    uint8_t  dq_flags, dq_qp, log2_matrix_size;
+    uint64_t scale_matrix;
+    int16_t  dc;
+    uint8_t  pad_[6];
 } vvc355_itx_job;
 
 /* max_log2_area = max over the batch of log2_w + log2_h; it selects the lanes-per-block mapping (<= 6: a wave per block) */

@@ -99,6 +99,7 @@ def _itx_frame_case(dev, orc, bd, rng, shapes, n_per_shape, wild):
             d_pic = batch.DeviceBuffer.from_host(pitched)
             coeffs = np.zeros((n_per_shape, h, w), np.int32)
             arr = (abi.ItxJob * n_per_shape)()
+            dq_bufs = []
             for i in range(n_per_shape):
                 trh = int(rng.integers(0, 3)) if 4 <= w <= 32 else DCT2
                 trv = int(rng.integers(0, 3)) if 4 <= h <= 32 else DCT2
@@ -119,9 +120,19 @@ def _itx_frame_case(dev, orc, bd, rng, shapes, n_per_shape, wild):
                     keep[:cntv, :nzw] = True
                     c = np.where(keep, c, g).astype(np.int32)
                     # the reference does read rows nz..cntv-1 inside the window: keep those as they are in both runs
+                # half of the regular jobs carry levels and ask for the fused scaling process (dequant) at load time
+                fused = rbits == 15 and rng.random() < 0.5
+                if fused:
+                    c = np.where(c != 0, rng.integers(-(1 << 9), 1 << 9, size=c.shape), 0).astype(np.int32)
+                    qp, dep = int(rng.integers(0, 64)), int(rng.integers(0, 2))
+                    lm = int(rng.choice([1, 2, 3]))
+                    sm = rng.integers(1, 256, size=(1 << (2 * lm),)).astype(np.uint8) if rng.random() < 0.5 else None
+                    dc = int(rng.integers(1, 256)) if (sm is not None and rng.random() < 0.5) else -1
                 coeffs[i] = c
                 x0, y0 = (i % cols) * w, (i // cols) * h
                 ref = c.copy()
+                if fused:
+                    orc.orc_dequant(P(ref), lw, lh, 0, 0, w - 1, h - 1, qp, 0, dep, bd, 15, P(sm) if sm is not None else None, lm, dc)
                 assert orc.orc_itx(trh, trv, lw, lh, P(ref), nzw, nzh, rbits, bd) == 0
                 blk = np.ascontiguousarray(want[y0:y0 + h, x0:x0 + w])
                 orc.orc_add_residual(bd, P(blk), P(ref), w, h, w * isz)
@@ -129,6 +140,11 @@ def _itx_frame_case(dev, orc, bd, rng, shapes, n_per_shape, wild):
                 j = arr[i]
                 j.dst, j.dst_stride = d_pic.ptr + y0 * pitch + x0 * isz, pitch
                 j.trh, j.trv, j.log2_w, j.log2_h, j.nzw, j.nzh, j.range, j.bd = trh, trv, lw, lh, nzw, nzh, rbits, bd
+                if fused:
+                    j.dq_flags, j.dq_qp, j.log2_matrix_size, j.dc = 1 | (dep << 1), qp, lm, dc
+                    if sm is not None:
+                        dq_bufs.append(batch.DeviceBuffer.from_host(sm))
+                        j.scale_matrix = dq_bufs[-1].ptr
             d_c = batch.DeviceBuffer.from_host(coeffs)
             for i in range(n_per_shape):
                 arr[i].coeffs = d_c.ptr + i * w * h * 4

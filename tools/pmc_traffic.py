@@ -18,8 +18,7 @@ import sys
 STAGES = {                      # stage name of bench.py -> substring of the kernel name
     "inter_pred_bi_dmvr_bdof": "bipred_kernel",
     "intra_pred": "intra_pred_kernel",
-    "dequant": "dequant_kernel",
-    "itx_add_residual": "itx_shape_kernel",
+    "dequant_itx_add_residual": "itx_shape_kernel",
     "lmcs_inverse_luma": "lmcs_kernel",
     "deblock_vertical": "deblock_kernel",       # first deblock launch of a step
     "deblock_horizontal": "deblock_kernel",     # second one
