@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void pred_fused_kernel(const vvc355_pred_job *
     const int ji = blockIdx.x * 4 + wave;
     if (ji >= n_jobs)
         return;
-    const vvc355_pred_job *job = jobs + ji;              // wave-uniform address
+    const vvc355_pred_job job_copy = jobs[ji];           // wave-uniform address: scalar dword loads, fields unpacked on the SALU
+    const vvc355_pred_job *job = &job_copy;
     const int w = job->w, h = job->h, mode = job->mode, frac = job->frac;
     const int lw = 31 - __builtin_clz(w);
     int v0[4], v1[4] = { 0, 0, 0, 0 };
@@ -283,6 +284,41 @@ __device__ __forceinline__ void store_rows(uint16_t *win, int lane, const uint16
             if ((lane >> 5) + 2 * it < kWinH)
                 q[it * 2 * kWinW] = v[it];
     }
+}
+
+// Unclamped form for windows that lie inside their readable rectangle (the common case): a lane moves 4 consecutive samples
+// per step (one 8-byte load, one ds_write_b64), kWinW / 4 = 6 vectors per row: 3 steps cover a 23-row window, instead of 12
+// one-sample steps.  fetch_vec4 only issues the loads (both references' loads go out before anything waits), put_vec4 stores.
+template <int BD, int NV>
+__device__ __forceinline__ void fetch_vec4(const uint8_t *plane, int stride, int wx0, int wy0, int nrows, int lane, uint2 (&v)[NV])
+{
+    using px_t = typename Px<BD>::type;
+    const uint8_t *org = plane + (ptrdiff_t)wy0 * stride + wx0 * (int)sizeof(px_t);
+#pragma unroll
+    for (int it = 0; it < NV; it++) {
+        const int id = lane + 64 * it, r = min(id / 6, nrows - 1), k = id - (id / 6) * 6;    // rows past the window re-read its last row
+        const uint8_t *p = org + (ptrdiff_t)r * stride + k * 4 * (int)sizeof(px_t);
+        if (BD > 8) {
+            v[it] = gld<uint2>(p);
+        } else {
+            const uint32_t q = gld<uint32_t>(p);
+            v[it] = make_uint2(__builtin_amdgcn_perm(0, q, 0x0c010c00u), __builtin_amdgcn_perm(0, q, 0x0c030c02u));
+        }
+    }
+}
+template <int NV>
+__device__ __forceinline__ void put_vec4(uint16_t *win, int nrows, int lane, const uint2 (&v)[NV])
+{
+#pragma unroll
+    for (int it = 0; it < NV; it++) {
+        const int id = lane + 64 * it, r = id / 6, k = id - r * 6;
+        if (r < nrows)
+            *(uint2 *)(win + r * kWinW + 4 * k) = v[it];
+    }
+}
+__device__ __forceinline__ bool rect_holds(const ClampRect &rc, int wx0, int wy0, int nrows)
+{
+    return wx0 >= rc.x0 && wx0 + kWinW - 1 <= rc.x1 && wy0 >= rc.y0 && wy0 + nrows - 1 <= rc.y1;
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -356,11 +392,20 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
     const ClampRect pic = { 0, 0, job->pic_w - 1, job->pic_h - 1 };
     {
         // (pw + 1) x (ph + 1) integer samples around each reference block, two rows back (emulated_edge_bilinear :90-110)
-        uint16_t r0[11], r1[11];
-        fetch_clamped<BD, 11>((const uint8_t *)job->ref0, job->ref0_stride, pic, job->x + (mv[0] >> 4) - 2, job->y + (mv[1] >> 4) - 2, lane, r0);
-        fetch_clamped<BD, 11>((const uint8_t *)job->ref1, job->ref1_stride, pic, job->x + (mv[2] >> 4) - 2, job->y + (mv[3] >> 4) - 2, lane, r1);
-        store_rows<11>(L.win[0], lane, r0);
-        store_rows<11>(L.win[1], lane, r1);
+        const int ax = job->x + (mv[0] >> 4) - 2, ay = job->y + (mv[1] >> 4) - 2, bx = job->x + (mv[2] >> 4) - 2, by = job->y + (mv[3] >> 4) - 2;
+        if (rect_holds(pic, ax, ay, ph + 1) && rect_holds(pic, bx, by, ph + 1)) {
+            uint2 q0[2], q1[2];                              // 21 rows x 6 vectors = 126 <= 128
+            fetch_vec4<BD, 2>((const uint8_t *)job->ref0, job->ref0_stride, ax, ay, ph + 1, lane, q0);
+            fetch_vec4<BD, 2>((const uint8_t *)job->ref1, job->ref1_stride, bx, by, ph + 1, lane, q1);
+            put_vec4<2>(L.win[0], ph + 1, lane, q0);
+            put_vec4<2>(L.win[1], ph + 1, lane, q1);
+        } else {
+            uint16_t r0[11], r1[11];
+            fetch_clamped<BD, 11>((const uint8_t *)job->ref0, job->ref0_stride, pic, ax, ay, lane, r0);
+            fetch_clamped<BD, 11>((const uint8_t *)job->ref1, job->ref1_stride, pic, bx, by, lane, r1);
+            store_rows<11>(L.win[0], lane, r0);
+            store_rows<11>(L.win[1], lane, r1);
+        }
         wave_sync();
     }
     // inter.dmvr[!!my][!!mx] (vvc_inter_template.c:324-413).  Lane -> (reference, pair of adjacent columns, segment of rows):
@@ -608,11 +653,22 @@ __device__ __forceinline__ void predict_clamped(const vvc355_bipred_job *job, Bi
 {
     constexpr int LEAD = NTAP == 8 ? 3 : 1, NIT = (16 + NTAP) / 2;
     {
-        uint16_t r0[NIT], r1[NIT];
-        fetch_clamped<BD, NIT>((const uint8_t *)job->ref0, job->ref0_stride, rc[0], ox[0] - LEAD, oy[0] - (fy[0] ? LEAD : 0), lane, r0);
-        fetch_clamped<BD, NIT>((const uint8_t *)job->ref1, job->ref1_stride, rc[1], ox[1] - LEAD, oy[1] - (fy[1] ? LEAD : 0), lane, r1);
-        store_rows<NIT>(L.win[0], lane, r0);
-        store_rows<NIT>(L.win[1], lane, r1);
+        const int ax = ox[0] - LEAD, ay = oy[0] - (fy[0] ? LEAD : 0), an = fy[0] ? h + NTAP - 1 : h;
+        const int bx = ox[1] - LEAD, by = oy[1] - (fy[1] ? LEAD : 0), bn = fy[1] ? h + NTAP - 1 : h;
+        if (rect_holds(rc[0], ax, ay, an) && rect_holds(rc[1], bx, by, bn)) {
+            constexpr int NV = NTAP == 8 ? 3 : 2;            // 23 x 6 = 138 <= 192 (luma), 19 x 6 = 114 <= 128 (chroma, h <= 16)
+            uint2 q0[NV], q1[NV];
+            fetch_vec4<BD, NV>((const uint8_t *)job->ref0, job->ref0_stride, ax, ay, an, lane, q0);
+            fetch_vec4<BD, NV>((const uint8_t *)job->ref1, job->ref1_stride, bx, by, bn, lane, q1);
+            put_vec4<NV>(L.win[0], an, lane, q0);
+            put_vec4<NV>(L.win[1], bn, lane, q1);
+        } else {
+            uint16_t r0[NIT], r1[NIT];
+            fetch_clamped<BD, NIT>((const uint8_t *)job->ref0, job->ref0_stride, rc[0], ax, ay, lane, r0);
+            fetch_clamped<BD, NIT>((const uint8_t *)job->ref1, job->ref1_stride, rc[1], bx, by, lane, r1);
+            store_rows<NIT>(L.win[0], lane, r0);
+            store_rows<NIT>(L.win[1], lane, r1);
+        }
         wave_sync();
     }
     uint32_t t[2][4];       // hf lo/hi, vf lo/hi per reference
@@ -645,7 +701,10 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
     const int ji = blockIdx.x * 4 + wave;
     if (ji >= n_jobs)
         return;
-    const vvc355_bipred_job *job = jobs + ji;            // wave-uniform
+    // The descriptor is copied dword-wise at a wave-uniform address (scalar loads, issued once); reading its byte / short
+    // fields through the pointer would be a vector load with a full memory round trip at every point of use.
+    const vvc355_bipred_job job_copy = jobs[ji];
+    const vvc355_bipred_job *job = &job_copy;
     BipredLds &L = *(BipredLds *)&lds_all[wave];      // without TOOLS only win / tmpT are touched
     if (!TOOLS && !job->chroma)
         return;                                          // contract: a chroma-only launch holds chroma jobs
