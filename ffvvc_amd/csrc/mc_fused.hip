@@ -350,8 +350,8 @@ struct BipredLds {
             };
         };
         struct {
-            int16_t smp[2][kGs * kGs];
-            int16_t grad[4][kGs * kGs];                  // gh0, gh1, gv0, gv1
+            int16_t smp[2][kGs * kGs];                   // the two predictions + fetched ring
+            int16_t grad[5][kGs * kGs];                  // BDOF planes: D, TH, TV, GHD, GVD (see bdof_wave)
         };
     };
     int sad[28];
@@ -488,8 +488,13 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
                 const int16_t *b = plane(1, dx & 1) + (4 - dy) * kBilP + (4 - dx);
                 for (int r = half; 2 * r < h; r += 2) {
                     const uint32_t *ar = (const uint32_t *)(a + 2 * r * kBilP), *br = (const uint32_t *)(b + 2 * r * kBilP);
-                    for (int x = 0; 2 * x < w; x++)
-                        acc = __builtin_amdgcn_sad_u16(ar[x], br[x], acc);
+                    uint32_t va[8], vb[8];
+#pragma unroll
+                    for (int x = 0; x < 8; x++) { va[x] = ar[x]; vb[x] = br[x]; }      // 16 samples; both planes are 20 wide, so in range for w = 8 too
+#pragma unroll
+                    for (int x = 0; x < 8; x++)
+                        if (2 * x < w)
+                            acc = __builtin_amdgcn_sad_u16(va[x], vb[x], acc);
                 }
             }
             acc += __shfl_xor(acc, 1, 64);
@@ -537,7 +542,6 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
 {
     using px_t = typename Px<BD>::type;
     int16_t *smp0 = L.smp[0], *smp1 = L.smp[1];
-    int16_t *gh0 = L.grad[0], *gh1 = L.grad[1], *gv0 = L.grad[2], *gv1 = L.grad[3];
     {
         const int x = lane & 15;
 #pragma unroll
@@ -564,60 +568,64 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
         (p ? smp1 : smp0)[(y + 1) * kGs + x + 1] = (int16_t)(s << (14 - BD));
     }
     wave_sync();
-    // gradients of the interior (prof_grad_filter :135), lane -> column lane & 15, rows (lane >> 4) + 4 k
+    // What the sub-block sums and the output read are combinations of the two references' planes, so those are what is kept:
+    //   D = (s0 >> 4) - (s1 >> 4), TH = (gh0 + gh1) >> 1, TV = (gv0 + gv1) >> 1, GHD = gh0 - gh1, GVD = gv0 - gv1
+    // with gh / gv the gradients of prof_grad_filter (:135).  The reference replicates the rings of s and of every gradient plane
+    // (pad_int16, vvcdsp.c:29); replicating D, TH, TV is the same thing, and GHD / GVD / s are only read inside the block.
+    int16_t *pD = L.grad[0], *pTH = L.grad[1], *pTV = L.grad[2], *pGHD = L.grad[3], *pGVD = L.grad[4];
     {
         const int x = (lane & 15) + 1;
         if (x <= w)
             for (int y = (lane >> 4) + 1; y <= h; y += 4) {
                 const int o = y * kGs + x;
-                gh0[o] = (int16_t)((smp0[o + 1] >> 6) - (smp0[o - 1] >> 6));
-                gv0[o] = (int16_t)((smp0[o + kGs] >> 6) - (smp0[o - kGs] >> 6));
-                gh1[o] = (int16_t)((smp1[o + 1] >> 6) - (smp1[o - 1] >> 6));
-                gv1[o] = (int16_t)((smp1[o + kGs] >> 6) - (smp1[o - kGs] >> 6));
+                const int gh0 = (smp0[o + 1] >> 6) - (smp0[o - 1] >> 6), gv0 = (smp0[o + kGs] >> 6) - (smp0[o - kGs] >> 6);
+                const int gh1 = (smp1[o + 1] >> 6) - (smp1[o - 1] >> 6), gv1 = (smp1[o + kGs] >> 6) - (smp1[o - kGs] >> 6);
+                // the reference stores the gradients as int16 (no narrowing happens: |g| <= 2^9)
+                pD[o] = (int16_t)((smp0[o] >> 4) - (smp1[o] >> 4));
+                pTH[o] = (int16_t)((gh0 + gh1) >> 1);
+                pTV[o] = (int16_t)((gv0 + gv1) >> 1);
+                pGHD[o] = (int16_t)(gh0 - gh1);
+                pGVD[o] = (int16_t)(gv0 - gv1);
             }
     }
     wave_sync();
-    // replicate rings: left / right columns first, then whole top / bottom rows (pad_int16, vvcdsp.c:29)
+    // replicate rings: left / right columns first, then whole top / bottom rows
     if (lane < h) {
         const int o = (lane + 1) * kGs;
-        gh0[o] = gh0[o + 1]; gh0[o + w + 1] = gh0[o + w];
-        gh1[o] = gh1[o + 1]; gh1[o + w + 1] = gh1[o + w];
-        gv0[o] = gv0[o + 1]; gv0[o + w + 1] = gv0[o + w];
-        gv1[o] = gv1[o + 1]; gv1[o + w + 1] = gv1[o + w];
-        smp0[o] = smp0[o + 1]; smp0[o + w + 1] = smp0[o + w];
-        smp1[o] = smp1[o + 1]; smp1[o + w + 1] = smp1[o + w];
+        pD[o] = pD[o + 1]; pD[o + w + 1] = pD[o + w];
+        pTH[o] = pTH[o + 1]; pTH[o + w + 1] = pTH[o + w];
+        pTV[o] = pTV[o + 1]; pTV[o + w + 1] = pTV[o + w];
     }
     wave_sync();
     if (lane < w + 2) {
         const int t = lane, b = (h + 1) * kGs + lane;
-        gh0[t] = gh0[t + kGs]; gh0[b] = gh0[b - kGs];
-        gh1[t] = gh1[t + kGs]; gh1[b] = gh1[b - kGs];
-        gv0[t] = gv0[t + kGs]; gv0[b] = gv0[b - kGs];
-        gv1[t] = gv1[t + kGs]; gv1[b] = gv1[b - kGs];
-        smp0[t] = smp0[t + kGs]; smp0[b] = smp0[b - kGs];
-        smp1[t] = smp1[t + kGs]; smp1[b] = smp1[b - kGs];
+        pD[t] = pD[t + kGs]; pD[b] = pD[b - kGs];
+        pTH[t] = pTH[t + kGs]; pTH[b] = pTH[b - kGs];
+        pTV[t] = pTV[t + kGs]; pTV[b] = pTV[b - kGs];
     }
     wave_sync();
     // four lanes per 4x4 sub-block, all (at most 16) sub-blocks at once (derive_bdof_vx_vy :237, apply_bdof_min_block :267):
-    // a lane sums 9 of the 36 window positions, two quad exchanges finish the sums, then it writes one row of the sub-block
+    // a lane sums one 3x3 quarter of the 6x6 window, two quad exchanges finish the sums, then it writes one row of the sub-block
     const int sbw = w >> 2, nsb = sbw * (h >> 2);
     const int sb = lane >> 2, q = lane & 3;
     if (sb >= nsb)
         return;                                          // whole quads leave together
     const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
     int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
+    {
+        const int o0 = (by + 3 * (q >> 1)) * kGs + bx + 3 * (q & 1);
 #pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const int e = q + 4 * t, j = e / 6, i = e - j * 6;
-        const int o = (by + j) * kGs + bx + i;
-        const int diff = (smp0[o] >> 4) - (smp1[o] >> 4);
-        const int th = (gh0[o] + gh1[o]) >> 1;
-        const int tv = (gv0[o] + gv1[o]) >> 1;
-        sgx2 += abs(th);
-        sgy2 += abs(tv);
-        sgxgy += sign_of(tv) * th;
-        sgxdi += -sign_of(th) * diff;
-        sgydi += -sign_of(tv) * diff;
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int o = o0 + j * kGs + i;
+                const int diff = pD[o], th = pTH[o], tv = pTV[o];
+                sgx2 += abs(th);
+                sgy2 += abs(tv);
+                sgxgy += sign_of(tv) * th;
+                sgxdi += -sign_of(th) * diff;
+                sgydi += -sign_of(tv) * diff;
+            }
     }
 #pragma unroll
     for (int m = 2; m >= 1; m >>= 1) {
@@ -636,7 +644,7 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int o = (py + 1) * kGs + bx + k + 1;
-        const int corr = vx * (gh0[o] - gh1[o]) + vy * (gv0[o] - gv1[o]);
+        const int corr = vx * pGHD[o] + vy * pGVD[o];
         out[k] = clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh);
     }
     if (BD > 8)
