@@ -142,7 +142,10 @@ def build_chain(lib, torch, fr):
         j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
         j["dmvr"], j["bdof"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
         bj.append(j)
-    luma_jobs, chroma_jobs = bj[0], np.concatenate(bj[1:])
+    # chroma jobs interleaved Cb, Cr, Cb, Cr, ...: the chroma launch predicts the two planes of a sub-block in one wave
+    luma_jobs = bj[0]
+    chroma_jobs = np.empty(2 * n_blk, dtype=bj[1].dtype)
+    chroma_jobs[0::2], chroma_jobs[1::2] = bj[1], bj[2]
     d_bl, d_bc = fr.upload(luma_jobs.view(np.uint8)), fr.upload(chroma_jobs.view(np.uint8))
     n_bl, n_bc = len(luma_jobs), len(chroma_jobs)
     inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)

@@ -115,7 +115,9 @@ __device__ __forceinline__ void store_window(uint16_t *win, int lane, const uint
 
 // One reference of one block, from its LDS window -> up to 4 intermediate values per lane (two row pairs of one column),
 // 14-bit scaled ints.  Result layout: column x = lane & 15, row pair yp = (lane >> 4) + 4 * i (i = 0, 1), rows 2yp, 2yp + 1.
-template <int BD, int NTAP>
+// SPLIT: the block is two 8-wide blocks of two planes side by side (outputs 0..7 | 8..15); the second plane's window starts
+// at window column 12 instead of 8, i.e. its outputs read 4 columns further right.
+template <int BD, int NTAP, bool SPLIT = false>
 __device__ __forceinline__ void interp_block(int lw, int h, bool hfrac, bool vfrac, uint32_t hf_lo, uint32_t hf_hi,
                                              uint32_t vf_lo, uint32_t vf_hi, const uint16_t *win, int16_t *tmpT, int lane, int (&val)[4])
 {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void interp_block(int lw, int h, bool hfrac, bool vfr
         const int n = sh << lhw;
         for (int i = lane; i < n; i += 64) {
             const int r = i >> lhw, xp = i & ((1 << lhw) - 1);                  // outputs x = 2*xp, 2*xp + 1
-            const uint32_t *d = (const uint32_t *)(win + r * kWinW + 2 * xp);   // tap 0 of output x sits at window index x: aligned
+            const uint32_t *d = (const uint32_t *)(win + r * kWinW + 2 * xp + (SPLIT && xp >= 4 ? 4 : 0));   // tap 0 of output x sits at window index x: aligned
             uint32_t dd[NO];
 #pragma unroll
             for (int m = 0; m < NO; m++) dd[m] = d[m];
@@ -144,7 +146,7 @@ __device__ __forceinline__ void interp_block(int lw, int h, bool hfrac, bool vfr
         const int n = sh << lw;
         for (int i = lane; i < n; i += 64) {
             const int r = i >> lw, x = i & (w - 1);
-            tmpT[x * kTmpP + r] = (int16_t)win[r * kWinW + x + LEAD];           // raw samples
+            tmpT[x * kTmpP + r] = (int16_t)win[r * kWinW + x + LEAD + (SPLIT && x >= 8 ? 4 : 0)];           // raw samples
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -702,18 +704,8 @@ struct BipredLdsLight {
 };
 
 template <int BD, bool TOOLS>
-__global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
+__device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredLds &L, int lane)
 {
-    __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLds, BipredLdsLight>::type lds_all[4];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ji = blockIdx.x * 4 + wave;
-    if (ji >= n_jobs)
-        return;
-    // The descriptor is copied dword-wise at a wave-uniform address (scalar loads, issued once); reading its byte / short
-    // fields through the pointer would be a vector load with a full memory round trip at every point of use.
-    const vvc355_bipred_job job_copy = jobs[ji];
-    const vvc355_bipred_job *job = &job_copy;
-    BipredLds &L = *(BipredLds *)&lds_all[wave];      // without TOOLS only win / tmpT are touched
     if (!TOOLS && !job->chroma)
         return;                                          // contract: a chroma-only launch holds chroma jobs
     const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr;
@@ -785,6 +777,128 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
     }
 }
 
+template <int BD, bool TOOLS>
+__global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
+{
+    __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLds, BipredLdsLight>::type lds_all[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ji = blockIdx.x * 4 + wave;
+    if (ji >= n_jobs)
+        return;
+    // The descriptor is copied dword-wise at a wave-uniform address (scalar loads, issued once); reading its byte / short
+    // fields through the pointer would be a vector load with a full memory round trip at every point of use.
+    const vvc355_bipred_job job_copy = jobs[ji];
+    bipred_one<BD, TOOLS>(&job_copy, *(BipredLds *)&lds_all[wave], lane);      // without TOOLS only win / tmpT are touched
+}
+
+// Chroma launch: one wave per PAIR of consecutive jobs.  When the two are the Cb and Cr blocks of one sub-block (same
+// geometry and motion, width <= 8) they are predicted together as one 16-wide block whose halves come from two planes —
+// an 8x8 block alone leaves half of the lanes of the vertical pass and of the window fetch idle.  Any other pair is done one
+// job after the other.
+template <int BD>
+__global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
+{
+    __shared__ __attribute__((aligned(16))) BipredLdsLight lds_all[4];
+    using px_t = typename Px<BD>::type;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ia = 2 * (blockIdx.x * 4 + wave);
+    if (ia >= n_jobs)
+        return;
+    const bool has_b = ia + 1 < n_jobs;
+    const vvc355_bipred_job ja = jobs[ia], jb = jobs[has_b ? ia + 1 : ia];
+    BipredLds &L = *(BipredLds *)&lds_all[wave];
+    bool pair = has_b && ja.chroma && jb.chroma && ja.w <= 8 && ja.w == jb.w && ja.h == jb.h && ja.x == jb.x && ja.y == jb.y &&
+                ja.rec == jb.rec && ja.hs == jb.hs && ja.vs == jb.vs && ja.dmvr == jb.dmvr && ja.hf_idx == jb.hf_idx &&
+                ja.vf_idx == jb.vf_idx && ja.pic_w == jb.pic_w && ja.pic_h == jb.pic_h;
+#pragma unroll
+    for (int k = 0; k < 4; k++) pair = pair && ja.mv[k] == jb.mv[k];
+    if (!pair) {
+        bipred_one<BD, false>(&ja, L, lane);
+        if (has_b) {
+            wave_sync();
+            bipred_one<BD, false>(&jb, L, lane);
+        }
+        return;
+    }
+    const vvc355_bipred_job *job = &ja;
+    const int w = job->w, h = job->h, dmvr = job->dmvr;
+    const vvc355_bipred_result *rec = (const vvc355_bipred_result *)job->rec;
+    int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
+    if (rec) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) mv[k] = rec->mv[k];                  // written by the luma launch: plain (scalar) loads
+    }
+    const int shx = 4 + job->hs, shy = 4 + job->vs;
+    int ox[2], oy[2], fx[2], fy[2];
+    ClampRect rc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int mvx = mv[2 * i], mvy = mv[2 * i + 1];
+        fx[i] = (mvx & ((1 << shx) - 1)) << (1 - job->hs);
+        fy[i] = (mvy & ((1 << shy) - 1)) << (1 - job->vs);
+        ox[i] = job->x + (mvx >> shx);
+        oy[i] = job->y + (mvy >> shy);
+        rc[i] = ClampRect{ 0, 0, job->pic_w - 1, job->pic_h - 1 };
+        if (dmvr) {
+            const int x_sb = job->x + (job->mv[2 * i] >> shx), y_sb = job->y + (job->mv[2 * i + 1] >> shy);
+            rc[i].x0 = min(max(x_sb - 1, 0), job->pic_w - 1);
+            rc[i].y0 = min(max(y_sb - 1, 0), job->pic_h - 1);
+            rc[i].x1 = rc[i].x0 + max(min((int)job->pic_w, x_sb + w + 2) - rc[i].x0, 1) - 1;
+            rc[i].y1 = rc[i].y0 + max(min((int)job->pic_h, y_sb + h + 2) - rc[i].y0, 1) - 1;
+        }
+    }
+    // windows: columns 0..11 from the first plane, 12..23 from the second, both starting one sample left of the block
+    {
+        const int c = lane & 31, second = c >= 12, cc = c - (second ? 12 : 0);
+        uint16_t r[2][10];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint8_t *pa = (const uint8_t *)(i ? ja.ref1 : ja.ref0), *pb = (const uint8_t *)(i ? jb.ref1 : jb.ref0);
+            const int sa = i ? ja.ref1_stride : ja.ref0_stride, sb = i ? jb.ref1_stride : jb.ref0_stride;
+            const uint8_t *plane = second ? pb : pa;
+            const int stride = second ? sb : sa;
+            const int xa = clip3(ox[i] - 1 + cc, rc[i].x0, rc[i].x1);
+            const uint8_t *col = plane + (ptrdiff_t)xa * (int)sizeof(px_t);
+            const int wy0 = oy[i] - (fy[i] ? 1 : 0);
+#pragma unroll
+            for (int it = 0; it < 10; it++) {
+                const int ya = clip3(wy0 + (lane >> 5) + 2 * it, rc[i].y0, rc[i].y1);
+                r[i][it] = (uint16_t)gld<px_t>(col + (ptrdiff_t)ya * stride);
+            }
+        }
+        store_rows<10>(L.win[0], lane, r[0]);
+        store_rows<10>(L.win[1], lane, r[1]);
+        wave_sync();
+    }
+    uint32_t t[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        t[i][0] = gld<uint32_t>(d_tab_inter_chroma_filters + (job->hf_idx * 32 + fx[i]) * 4);
+        t[i][1] = gld<uint32_t>(d_tab_inter_chroma_filters + (job->vf_idx * 32 + fy[i]) * 4);
+    }
+    int v0[4], v1[4];
+    interp_block<BD, 4, true>(4, h, fx[0] != 0, fy[0] != 0, t[0][0], 0, t[0][1], 0, L.win[0], L.tmpT, lane, v0);
+    interp_block<BD, 4, true>(4, h, fx[1] != 0, fy[1] != 0, t[1][0], 0, t[1][1], 0, L.win[1], L.tmpT, lane, v1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v0[i] = (int16_t)v0[i]; v1[i] = (int16_t)v1[i]; }     // put[..] stores int16
+    // lanes 0..7 of a row write the first plane, 8..15 the second, each with its own weights
+    const int x = lane & 15, second = x >= 8, xo = x - (second ? 8 : 0);
+    const int wf = second ? jb.weight_flag : ja.weight_flag, w0 = second ? jb.w0 : ja.w0, w1 = second ? jb.w1 : ja.w1;
+    const int denom = second ? jb.denom : ja.denom, osum = second ? jb.o0 + jb.o1 : ja.o0 + ja.o1;
+    const int shift = wf ? denom + max(3, 15 - BD) : max(3, 15 - BD);
+    const int off = wf ? ((osum << (BD - 8)) + 1) << (shift - 1) : 1 << (shift - 1);
+    uint8_t *dst = (uint8_t *)(second ? jb.dst : ja.dst);
+    const int dst_stride = second ? jb.dst_stride : ja.dst_stride;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+        if (xo >= w || y >= h)
+            continue;
+        const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
+        st_px<BD>(dst + (ptrdiff_t)y * dst_stride, xo, clip_px<BD>(p));
+    }
+}
+
 } // namespace vvc355
 
 extern "C" void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_job *jobs_dev, int n_jobs)
@@ -807,6 +921,7 @@ extern "C" void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bi
 {
     using namespace vvc355;
     if (n_jobs <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD, false>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
+    const int n_pairs = (n_jobs + 1) / 2;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_chroma_pair_kernel<BD>), dim3((n_pairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
     HIP_CHECK(hipGetLastError());
 }

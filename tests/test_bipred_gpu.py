@@ -91,6 +91,13 @@ def test_bipred_frame(dev, orc, bd):
             luma[nl] = dj; nl += 1
         else:
             chroma[nc] = dj; nc += 1
+    if bd == 12:
+        # break the (Cb, Cr) pairing of consecutive jobs: the chroma launch must then take its one-job-at-a-time path
+        order = rng.permutation(nc)
+        shuffled = (abi.BipredJob * (2 * n))()
+        for k, o in enumerate(order):
+            shuffled[k] = chroma[int(o)]
+        chroma = shuffled
     d_l, d_c = batch.jobs_to_device(luma), batch.jobs_to_device(chroma)
     dev.vvc355_bipred_batch(None, bd, d_l.ptr, nl)
     (dev.vvc355_bipred_chroma_batch if bd != 8 else dev.vvc355_bipred_batch)(None, bd, d_c.ptr, nc)     # both entries
