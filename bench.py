@@ -175,12 +175,17 @@ def build_chain(lib, torch, fr):
         j["plane_w"], j["plane_h"], j["c_idx"] = w, h, c
         j["cand_up_left"] = (x0 > 0) & (y0 > 0)
         ij.append(j)
-    intra_all = np.concatenate(ij)
-    d_intra = fr.upload(intra_all.view(np.uint8))
-    n_intra = len(intra_all)
+    # two launches by block area: 16x16 luma TUs (a wave per block), 8x8 chroma TUs of both planes (half a wave per block)
+    intra_luma, intra_chroma = ij[0], np.concatenate(ij[1:])
+    d_il, d_ic = fr.upload(intra_luma.view(np.uint8)), fr.upload(intra_chroma.view(np.uint8))
+    n_il, n_ic = len(intra_luma), len(intra_chroma)
     intra_samples = sum(int(len(j)) * int(j["w"][0]) ** 2 for j in ij)
-    chain.append(Stage("intra_pred", f"intra_pred_kernel<{bd}>", lambda st: lib.vvc355_intra_pred_batch(st, bd, ptr(d_intra), n_intra, 8),
-                       intra_samples * isz))
+
+    def launch_intra(st):
+        lib.vvc355_intra_pred_batch(st, bd, ptr(d_il), n_il, 8)
+        lib.vvc355_intra_pred_batch(st, bd, ptr(d_ic), n_ic, 6)
+
+    chain.append(Stage("intra_pred", f"intra_pred_kernel<{bd}, *>", launch_intra, intra_samples * isz))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape

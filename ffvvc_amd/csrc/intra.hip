@@ -77,7 +77,7 @@ struct LRef {
 
 template <int NT> __device__ __forceinline__ void group_sync()
 {
-    if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if (NT <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }     // the group sits inside one wave
     else __syncthreads();
 }
 
@@ -86,7 +86,7 @@ __device__ void pred_planar(int tid, uint8_t *src, ptrdiff_t stride, R top, R le
 {
     const int lw = ilog2i(w), lh = ilog2i(h);
     for (int i = tid; i < w * h; i += NT) {
-        const int y = i / w, x = i - y * w;
+        const int y = i >> lw, x = i & (w - 1);           // block sides are powers of two
         const int pv = ((h - 1 - y) * top(x) + (y + 1) * left(h)) << lw;
         const int ph = ((w - 1 - x) * left(y) + (x + 1) * top(w)) << lh;
         st_px<BD>(src, x + stride * y, (pv + ph + w * h) >> (lw + lh + 1));
@@ -105,8 +105,9 @@ __device__ void pred_dc(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, 
     }
     group_sync<NT>();
     const int dc = *scratch, w4 = (w + 3) & ~3;          // stores cover whole groups of 4 (:856)
+    const int lw4 = ilog2i(w4);
     for (int i = tid; i < w4 * h; i += NT) {
-        const int y = i / w4, x = i - y * w4;
+        const int y = i >> lw4, x = i & (w4 - 1);
         st_px<BD>(src, x + stride * y, dc);
     }
 }
@@ -115,8 +116,9 @@ template <int BD, int NT, typename R>
 __device__ void pred_vh(int tid, uint8_t *src, ptrdiff_t stride, R ref, int w, int h, bool vertical)
 {
     const int ww = vertical ? w : (w + 3) & ~3;           // pred_h stores whole groups of 4 (:885)
+    const int lww = ilog2i(ww);
     for (int i = tid; i < ww * h; i += NT) {
-        const int y = i / ww, x = i - y * ww;
+        const int y = i >> lww, x = i & (ww - 1);
         st_px<BD>(src, x + stride * y, vertical ? ref(x) : ref(y));
     }
 }
@@ -143,9 +145,9 @@ __device__ void pred_angular(int tid, uint8_t *src, ptrdiff_t stride, R top, R l
         inv = intra_inv_angle(angle);
         nscale = intra_nscale(w, h, mode);
     }
-    const int base = -(1 + ref_idx);
+    const int base = -(1 + ref_idx), lw = ilog2i(w);
     for (int i = tid; i < w * h; i += NT) {
-        const int y = i / w, x = i - y * w;
+        const int y = i >> lw, x = i & (w - 1);
         const int along = vertical ? x : y, across = vertical ? y : x;
         const int pos = (1 + ref_idx + across) * angle;
         const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
@@ -178,9 +180,9 @@ __device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left,
                                          : i_tab_mip_matrix_16x16 + mode_id * 64 * 7;
     const int up_h = w / psize, up_v = h / psize;
     group_sync<NT>();
-    if (tid < 2 * bsize) {
+    for (int k = tid; k < 2 * bsize; k += NT) {
         // boundary down-sampling: first bsize entries from the top row (left column when transposed), then the other side
-        const int k = tid, second = k >= bsize, from_top = second == (transposed != 0);
+        const int second = k >= bsize, from_top = second == (transposed != 0);
         const int len = from_top ? w : h, per = len / bsize, i0 = (k - second * bsize) * per;
         int s = 0;
         for (int j = 0; j < per; j++)
@@ -199,8 +201,8 @@ __device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left,
         red[15] = t0;
     }
     group_sync<NT>();
-    if (tid < psize * psize) {
-        const int y = tid / psize, x = tid - y * psize;
+    for (int t = tid; t < psize * psize; t += NT) {
+        const int y = t / psize, x = t - y * psize;
         int p = 0;
         for (int i = 0; i < in_size; i++)
             p += red[i] * matrix[(y * psize + x) * in_size + i];
@@ -209,8 +211,8 @@ __device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left,
         st_px<BD>(src, (up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
     }
     group_sync<NT>();
-    if (up_h > 1 && tid < psize) {            // one lane per row that holds reduced samples
-        const int row = up_v - 1 + tid * up_v;
+    for (int t = tid; up_h > 1 && t < psize; t += NT) {            // one lane per row that holds reduced samples
+        const int row = up_v - 1 + t * up_v;
         int before = left(row);
         for (int j = 0; j < psize; j++) {
             const int after = ld_px<BD>(src, (j + 1) * up_h - 1 + stride * row);
@@ -220,8 +222,7 @@ __device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left,
         }
     }
     group_sync<NT>();
-    if (up_v > 1 && tid < w) {                // one lane per column
-        const int x = tid;
+    for (int x = tid; up_v > 1 && x < w; x += NT) {                // one lane per column
         int before = top(x);
         for (int j = 0; j < psize; j++) {
             const int after = ld_px<BD>(src, x + stride * ((j + 1) * up_v - 1));
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
 // ------------------------------------------------------------------------------------------------ flattened intra_pred
 
 // vvc_intra_template.c:467-592 (edge preparation) + :595-683 (dispatch, PDPC); one workgroup per job.
-// NT = 64: one wave per block (w*h <= 256), four blocks per workgroup, wave-level synchronisation; NT = 256: one workgroup per block.
+// NT = 32: half a wave per block (w*h <= 64), eight blocks per workgroup; NT = 64: one wave per block (w*h <= 256), four per
+// workgroup; both with wave-level synchronisation only.  NT = 256: one workgroup per block.
 template <int BD, int NT>
 __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs, int n_jobs)
 {
@@ -366,8 +368,9 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
     if (need_pdpc && !is_mip && (mode == 0 || mode == 1 || mode == 50 || mode == 18)) {      // :654-682
         group_sync<NT>();
         const int scale = (ilog2i(w) + ilog2i(h) - 2) >> 2;
+        const int lw = ilog2i(w);
         for (int i = tid; i < w * h; i += NT) {
-            const int y = i / w, x = i - y * w;
+            const int y = i >> lw, x = i & (w - 1);
             const int val = GETP(x, y);
             int l, t, wl, wt;
             if (mode == 0 || mode == 1) {
@@ -465,7 +468,8 @@ void vvc355_intra_pred_batch(void *stream, int bd, const vvc355_intra_job *jobs_
 {
     if (n_jobs <= 0) return;
     VVC355_BD_DISPATCH(bd, {
-        if (max_log2_area <= 8) hipLaunchKernelGGL((intra_pred_kernel<BD, 64>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+        if (max_log2_area <= 6)      hipLaunchKernelGGL((intra_pred_kernel<BD, 32>), dim3((n_jobs + 7) / 8), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+        else if (max_log2_area <= 8) hipLaunchKernelGGL((intra_pred_kernel<BD, 64>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
         else                    hipLaunchKernelGGL((intra_pred_kernel<BD, 256>), dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
     });
     HIP_CHECK(hipGetLastError());
