@@ -56,6 +56,23 @@ template <typename T> __device__ __forceinline__ void gst(void *p, T v)
     *(VVC355_GLOBAL raw_t *)p = r;
 }
 
+// A job descriptor at a wave-uniform address, fetched with scalar loads (s_load_dwordx*): the constant address space tells the
+// compiler that the scalar cache may be used.  A plain struct copy is split into per-field loads, and byte / short fields make
+// those vector loads: a full vector-memory round trip before the kernel can even compute its first pixel address.
+#define VVC355_CONST __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ T load_uniform(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "job descriptors are whole dwords");
+    constexpr int N = sizeof(T) / 4;
+    uint32_t w[N];
+    const VVC355_CONST uint32_t *q = (const VVC355_CONST uint32_t *)p;
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = q[i];
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+
 // pixel load / store on HBM planes (never on LDS)
 template <int BD> __device__ __forceinline__ int ld_px(const uint8_t *p, ptrdiff_t i)
 {

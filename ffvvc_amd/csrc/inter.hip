@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void mc_kernel(const vvc355_mc_job *__restrict
 {
     __shared__ uint16_t s[kMcTile + 7][kMcSrcW];
     __shared__ int16_t t[kMcTile + 7][kMcTile];
-    const vvc355_mc_job job = jobs[blockIdx.y];
+    const vvc355_mc_job job = load_uniform(jobs + (blockIdx.y));
     const int tiles_x = (job.w + kMcTile - 1) / kMcTile, tiles_y = (job.h + kMcTile - 1) / kMcTile;
     if ((int)blockIdx.x >= tiles_x * tiles_y)
         return;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void mc_kernel(const vvc355_mc_job *__restrict
 template <int BD>
 __global__ __launch_bounds__(256) void blend_kernel(const vvc355_blend_job *__restrict__ jobs)
 {
-    const vvc355_blend_job job = jobs[blockIdx.y];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.y));
     const int w = job.w, h = job.h, mode = job.mode;
     uint8_t *dst = (uint8_t *)job.dst;
     const int s0 = job.src0_stride, s1 = job.src1_stride;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void bdof_kernel(const vvc355_blend_job *__res
     constexpr int GS = 18;
     __shared__ int16_t smp[2][GS][GS];        // samples incl. ring, (1,1) = block origin
     __shared__ int16_t gh[2][GS][GS], gv[2][GS][GS];
-    const vvc355_blend_job job = jobs[blockIdx.x];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.x));
     const int w = job.w, h = job.h, tid = threadIdx.x;
     int16_t *src[2] = { (int16_t *)job.src0, (int16_t *)job.src1 };
     const int stride[2] = { job.src0_stride >> 1, job.src1_stride >> 1 };
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void prof_kernel(const vvc355_blend_job *__res
 template <int BD>
 __global__ void fetch_ring_kernel(const vvc355_blend_job *__restrict__ jobs)
 {
-    const vvc355_blend_job job = jobs[blockIdx.x];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.x));
     const int w = job.w, h = job.h;
     const int x_off = (job.w0 >> 3) - 1, y_off = (job.w1 >> 3) - 1;
     const int ds = job.dst_stride >> 1;
@@ -319,7 +319,7 @@ __global__ void fetch_ring_kernel(const vvc355_blend_job *__restrict__ jobs)
 template <int BD>
 __global__ __launch_bounds__(256) void dmvr_kernel(const vvc355_mc_job *__restrict__ jobs)
 {
-    const vvc355_mc_job job = jobs[blockIdx.y];
+    const vvc355_mc_job job = load_uniform(jobs + (blockIdx.y));
     const int w = job.w, h = job.h, mx = job.hf[0], my = job.vf[0];
     const int hfrac = job.hfrac, vfrac = job.vfrac;
     const uint8_t *src = (const uint8_t *)job.src;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void dmvr_kernel(const vvc355_mc_job *__restri
 // vvc_sad (vvcdsp.c:49): one wave per job; out[job] = sum |a - b| over every other row
 __global__ __launch_bounds__(64) void sad_kernel(const vvc355_blend_job *__restrict__ jobs, int *out)
 {
-    const vvc355_blend_job job = jobs[blockIdx.x];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.x));
     const int s0 = job.src0_stride >> 1, s1 = job.src1_stride >> 1;
     const int dx = job.w0 - 2, dy = job.w1 - 2;
     const int16_t *a = (const int16_t *)job.src0 + (ptrdiff_t)(2 + dy) * s0 + 2 + dx;

@@ -562,7 +562,7 @@ template <int BD>
 __global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__restrict__ jobs)
 {
     __shared__ int prm[6];        // a[2], b[2], k[2]
-    const vvc355_cclm_job j = jobs[blockIdx.x];
+    const vvc355_cclm_job j = load_uniform(jobs + (blockIdx.x));
     using px_t = typename Px<BD>::type;
     const int hs = j.hs, vs = j.vs;
     const int x = j.x0 >> hs, y = j.y0 >> vs, w = j.width >> hs, h = j.height >> vs;

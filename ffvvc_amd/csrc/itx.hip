@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(const vvc355_dequant_job *
 template <int BD>
 __global__ __launch_bounds__(256) void residual_kernel(const vvc355_blend_job *__restrict__ jobs)
 {
-    const vvc355_blend_job job = jobs[blockIdx.y];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.y));
     int *res = (int *)job.src0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
         int r = res[i];
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void residual_kernel(const vvc355_blend_job *_
 // transform_bdpcm (:76): one lane per column (vertical) or row; job.dst = int coeffs, mode = vertical, denom = range
 __global__ __launch_bounds__(128) void bdpcm_kernel(const vvc355_blend_job *__restrict__ jobs)
 {
-    const vvc355_blend_job job = jobs[blockIdx.x];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.x));
     int *c = (int *)job.dst;
     const int w = job.w, h = job.h, range = job.denom, t = threadIdx.x;
     if (job.mode) {

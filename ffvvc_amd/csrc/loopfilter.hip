@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void lmcs_kernel(const vvc355_blend_job *__res
     using px_t = typename Px<BD>::type;
     constexpr int VB = 8 * (int)sizeof(px_t);                 // bytes per 8-sample vector
     __shared__ __attribute__((aligned(16))) px_t lut_lds[1 << BD];
-    const vvc355_blend_job job = jobs[blockIdx.y];
+    const vvc355_blend_job job = load_uniform(jobs + (blockIdx.y));
     const uint8_t *lut = (const uint8_t *)job.src0;
     if ((job.src0 & 15) == 0) {
         for (int i = threadIdx.x; i < (int)((sizeof(px_t) << BD) / 16); i += 256)
@@ -97,7 +97,7 @@ __device__ __forceinline__ bool sao_restore_px(const vvc355_sao_job &job, int x,
 template <int BD>
 __global__ __launch_bounds__(256) void sao_kernel(const vvc355_sao_job *__restrict__ jobs)
 {
-    const vvc355_sao_job job = jobs[blockIdx.y];
+    const vvc355_sao_job job = load_uniform(jobs + (blockIdx.y));
     const int w = job.w, h = job.h, type = job.type;
     const uint8_t *src = (const uint8_t *)job.src;
     const ptrdiff_t ss = job.src_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
@@ -192,18 +192,13 @@ template <int DX> __device__ __forceinline__ void shift8_pk(const uint32_t (&t)[
 
 struct SaoLut { uint32_t lo_a, lo_b, hi_a, hi_b; };      // bytes of the five offsets by category index 0..3 | 4
 
-// edge offset of 8 samples (h2656_sao_template.c:50-79): neighbours a / b one row up / down or in the same row (ra, rb point
-// at the samples above / below / beside x0), displaced by DXA / DXB columns
+// edge offset of 8 samples (h2656_sao_template.c:50-79) from registers: c = the samples, ta / tb = the aligned 8-sample vectors
+// of the rows that hold neighbours a / b, displaced by DXA / DXB columns (ea / eb = the sample just beyond the vector's end)
 template <int BD, int DXA, int DXB>
-__device__ __forceinline__ void sao_edge8(const typename Px<BD>::type *ra, const typename Px<BD>::type *rb, const uint32_t (&c)[4],
-                                          const SaoLut &lut, uint32_t (&out)[4])
+__device__ __forceinline__ void sao_edge8(const uint32_t (&c)[4], const uint32_t (&ta)[4], uint32_t ea, const uint32_t (&tb)[4],
+                                          uint32_t eb, const SaoLut &lut, uint32_t (&out)[4])
 {
-    using px_t = typename Px<BD>::type;
-    uint32_t ta[4], tb[4], a[4], b[4];
-    load8_pk<BD>(ra, ta);
-    load8_pk<BD>(rb, tb);
-    const uint32_t ea = DXA ? (uint32_t)gld<px_t>(ra + (DXA < 0 ? -1 : 8)) : 0u;
-    const uint32_t eb = DXB ? (uint32_t)gld<px_t>(rb + (DXB < 0 ? -1 : 8)) : 0u;
+    uint32_t a[4], b[4];
     shift8_pk<DXA>(ta, ea, a);
     shift8_pk<DXB>(tb, eb, b);
     const pk16 one = pk_splat(1), mone = pk_splat(-1), two = pk_splat(2), zero = pk_splat(0), top = pk_splat((1 << BD) - 1);
@@ -219,22 +214,23 @@ __device__ __forceinline__ void sao_edge8(const typename Px<BD>::type *ra, const
     }
 }
 
-// Vectorised form for the batched stage (types 1 and 3): a lane owns 8 consecutive samples of one row (one 16-byte load
-// / store per row at 10-bit), a workgroup 16 rows x 128 columns.  Only lanes that touch the rectangle's outer ring, where the
-// border / restore rules of sao_restore_px apply, take the per-sample path.
+// Vectorised form for the batched stage (types 1 and 3).  A lane owns 8 consecutive samples of FOUR consecutive rows: the six
+// row vectors it needs (one 16-byte load each at 10-bit) and the samples beside them are requested up front, so a wave has ~100 bytes per lane in flight and lives for one memory round trip per 2048
+// samples.  A workgroup covers 128 columns x 64 rows (narrower rectangles: fewer lanes across, more rows).  Only rows / lanes that
+// touch the rectangle's outer ring where a border / restore flag is set take the per-sample path of sao_restore_px.
 template <int BD>
 __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
 {
     using px_t = typename Px<BD>::type;
-    const vvc355_sao_job job = jobs[blockIdx.y];
+    const vvc355_sao_job job = load_uniform(jobs + blockIdx.y);
     const int w = job.w, h = job.h, type = job.type;
-    const int y = blockIdx.x * 16 + (threadIdx.x >> 4), x0 = (threadIdx.x & 15) * 8;
-    if (y >= h || x0 >= w)
+    const int lxl = w > 64 ? 4 : w > 32 ? 3 : w > 16 ? 2 : w > 8 ? 1 : 0;        // log2 of the lanes across
+    const int x0 = (threadIdx.x & ((1 << lxl) - 1)) * 8;
+    const int y0 = (blockIdx.x * (256 >> lxl) + (threadIdx.x >> lxl)) * 4;
+    if (y0 >= h || x0 >= w)
         return;
     const px_t *src = (const px_t *)job.src;
     const ptrdiff_t ss = job.src_stride / (ptrdiff_t)sizeof(px_t);
-    px_t *drow = (px_t *)((uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride);
-    const px_t *srow = src + (ptrdiff_t)y * ss;
     const int eo = job.eo & 3;
     const int dxa = kSaoNb[eo][0], dya = kSaoNb[eo][1], dxb = kSaoNb[eo][2], dyb = kSaoNb[eo][3];
     // the per-sample rules only matter where a border / restore flag of that side is set (or the vector is partial)
@@ -242,9 +238,12 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
     const bool f_r = job.borders[2] | job.vert_edge[1] | job.diag_edge[1] | job.diag_edge[2];
     const bool f_t = job.borders[1] | job.horiz_edge[0] | job.diag_edge[0] | job.diag_edge[1];
     const bool f_b = job.borders[3] | job.horiz_edge[1] | job.diag_edge[2] | job.diag_edge[3];
-    const bool ring = (x0 == 0 && f_l) || (x0 + 8 >= w && (f_r || x0 + 8 > w)) || (y == 0 && f_t) || (y == h - 1 && f_b);
-    if (type == 3 && ring) {
-        // per-sample path: picture borders, unfilterable slice / tile edges, partial vectors
+    const bool xring = (x0 == 0 && f_l) || (x0 + 8 >= w && (f_r || x0 + 8 > w));
+
+    auto per_sample_row = [&](int y) {
+        // picture borders, unfilterable slice / tile edges, partial vectors
+        const px_t *srow = src + (ptrdiff_t)y * ss;
+        px_t *drow = (px_t *)((uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride);
         for (int x = x0; x < min(x0 + 8, w); x++) {
             const int s = srow[x];
             int v;
@@ -254,25 +253,37 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
             }
             drow[x] = (px_t)v;
         }
-        return;
+    };
+    // rows y0 - 1 .. y0 + 4, clamped to the rows that may be read (a flagged top / bottom ring row never reads beyond itself)
+    uint32_t v[6][4];
+    const int ylo = f_t ? 0 : -1, yhi = f_b ? h - 1 : h;
+    const bool vert = type == 3 && eo != 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if ((k == 0 || k == 5) && !vert) {
+            v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0;
+            continue;
+        }
+        const int yk = min(max(y0 - 1 + k, ylo), yhi);
+        load8_pk<BD>(src + (ptrdiff_t)yk * ss + x0, v[k]);
     }
-    // the lane's 8 samples as four registers of two 16-bit samples each, whatever the storage type
-    uint32_t c[4], out[4];
-    load8_pk<BD>(srow + x0, c);
+    uint32_t out[4][4];
     if (type == 1) {
         int band[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) band[k] = (k + job.band_position) & 31;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int s = (c[j >> 1] >> ((j & 1) * 16)) & 0xffff;
-            const int b = (s >> (BD - 5)) & 31;
-            int off = 0;
+        for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
-            const uint32_t v = (uint32_t)clip_px<BD>(s + off);
-            out[j >> 1] = (j & 1) ? out[j >> 1] | (v << 16) : v;
-        }
+            for (int j = 0; j < 8; j++) {
+                const int s = (v[r + 1][j >> 1] >> ((j & 1) * 16)) & 0xffff;
+                const int b = (s >> (BD - 5)) & 31;
+                int off = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
+                const uint32_t pv = (uint32_t)clip_px<BD>(s + off);
+                out[r][j >> 1] = (j & 1) ? out[r][j >> 1] | (pv << 16) : pv;
+            }
     } else {
         // category -> offset as two byte look-ups (v_perm_b32): low bytes and high bytes of offset_val[kSaoCat[0..4]]
         uint32_t lo_a = 0, hi_a = 0;
@@ -284,18 +295,47 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
         }
         const uint32_t o4 = (uint16_t)job.offset_val[kSaoCat[4]];
         const SaoLut lut = { lo_a, o4 & 0xff, hi_a, o4 >> 8 };
-        const px_t *ra = srow + dya * ss + x0, *rb = srow + dyb * ss + x0;
-        switch (eo) {
-        case 0:  sao_edge8<BD, -1, 1>(ra, rb, c, lut, out); break;
-        case 1:  sao_edge8<BD, 0, 0>(ra, rb, c, lut, out); break;
-        case 2:  sao_edge8<BD, -1, 1>(ra, rb, c, lut, out); break;
-        default: sao_edge8<BD, 1, -1>(ra, rb, c, lut, out); break;
+        // the sample left / right of each row vector.  Loaded by every lane, unconditionally and right behind the row vectors,
+        // so that all of a wave's loads are in flight together (taking them from the neighbouring lanes' registers needs
+        // separate loads at the rectangle's first / last vector, and those cost the whole wave another memory round trip).
+        // On a flagged left / right ring the address is clamped into the rectangle; the value is not used there.
+        uint32_t eL[6], eR[6];
+        const int xl = (x0 == 0 && f_l) ? 0 : x0 - 1, xr = (x0 + 8 >= w && (f_r || x0 + 8 > w)) ? w - 1 : x0 + 8;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            eL[k] = eR[k] = 0;
+            if (eo == 1 || ((k == 0 || k == 5) && eo == 0))
+                continue;
+            const int yk = min(max(y0 - 1 + k, ylo), yhi);
+            eL[k] = (uint32_t)gld<px_t>(src + (ptrdiff_t)yk * ss + xl);
+            eR[k] = (uint32_t)gld<px_t>(src + (ptrdiff_t)yk * ss + xr);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = r + 1;
+            switch (eo) {
+            case 0:  sao_edge8<BD, -1, 1>(v[k], v[k], eL[k], v[k], eR[k], lut, out[r]); break;
+            case 1:  sao_edge8<BD, 0, 0>(v[k], v[k - 1], 0, v[k + 1], 0, lut, out[r]); break;
+            case 2:  sao_edge8<BD, -1, 1>(v[k], v[k - 1], eL[k - 1], v[k + 1], eR[k + 1], lut, out[r]); break;
+            default: sao_edge8<BD, 1, -1>(v[k], v[k - 1], eR[k - 1], v[k + 1], eL[k + 1], lut, out[r]); break;
+            }
         }
     }
-    if (x0 + 8 <= w) {
-        store8_pk<BD>(drow + x0, out);
-    } else {
-        for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)((out[j >> 1] >> ((j & 1) * 16)) & 0xffff);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = y0 + r;
+        if (y >= h)
+            break;
+        if (type == 3 && (xring || (y == 0 && f_t) || (y == h - 1 && f_b))) {
+            per_sample_row(y);
+            continue;
+        }
+        px_t *drow = (px_t *)((uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride);
+        if (x0 + 8 <= w) {
+            store8_pk<BD>(drow + x0, out[r]);
+        } else {
+            for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)((out[r][j >> 1] >> ((j & 1) * 16)) & 0xffff);
+        }
     }
 }
 
@@ -645,7 +685,7 @@ static void launch_sao(int bd, const vvc355_sao_job *jobs, int n, int max_w, int
 static void launch_sao_vec(int bd, const vvc355_sao_job *jobs, int n, int max_h, hipStream_t st)
 {
     if (n <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_vec_kernel<BD>), dim3((max_h + 15) / 16, n), dim3(256), 0, st, jobs));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_vec_kernel<BD>), dim3((max_h + 63) / 64, n), dim3(256), 0, st, jobs));
     HIP_CHECK(hipGetLastError());
 }
 

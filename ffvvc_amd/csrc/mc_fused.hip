@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void pred_fused_kernel(const vvc355_pred_job *
     const int ji = blockIdx.x * 4 + wave;
     if (ji >= n_jobs)
         return;
-    const vvc355_pred_job job_copy = jobs[ji];           // wave-uniform address: scalar dword loads, fields unpacked on the SALU
+    const vvc355_pred_job job_copy = load_uniform(jobs + ji);           // wave-uniform address: scalar dword loads, fields unpacked on the SALU
     const vvc355_pred_job *job = &job_copy;
     const int w = job->w, h = job->h, mode = job->mode, frac = job->frac;
     const int lw = 31 - __builtin_clz(w);
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
         return;
     // The descriptor is copied dword-wise at a wave-uniform address (scalar loads, issued once); reading its byte / short
     // fields through the pointer would be a vector load with a full memory round trip at every point of use.
-    const vvc355_bipred_job job_copy = jobs[ji];
+    const vvc355_bipred_job job_copy = load_uniform(jobs + ji);
     bipred_one<BD, TOOLS>(&job_copy, *(BipredLds *)&lds_all[wave], lane);      // without TOOLS only win / tmpT are touched
 }
 
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bi
     if (ia >= n_jobs)
         return;
     const bool has_b = ia + 1 < n_jobs;
-    const vvc355_bipred_job ja = jobs[ia], jb = jobs[has_b ? ia + 1 : ia];
+    const vvc355_bipred_job ja = load_uniform(jobs + ia), jb = load_uniform(jobs + (has_b ? ia + 1 : ia));
     BipredLds &L = *(BipredLds *)&lds_all[wave];
     bool pair = has_b && ja.chroma && jb.chroma && ja.w <= 8 && ja.w == jb.w && ja.h == jb.h && ja.x == jb.x && ja.y == jb.y &&
                 ja.rec == jb.rec && ja.hs == jb.hs && ja.vs == jb.vs && ja.dmvr == jb.dmvr && ja.hf_idx == jb.hf_idx &&
