@@ -32,7 +32,7 @@ __device__ static const uint8_t kAlfVarTab[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3,
 __device__ static constexpr int8_t kLumaTap[12][2] = {
     { 3, 0 }, { 2, 1 }, { 2, 0 }, { 2, -1 }, { 1, 2 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 1, -2 }, { 0, 3 }, { 0, 2 }, { 0, 1 },
 };
-__device__ static const int8_t kChromaTap[6][2] = { { 2, 0 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 0, 2 }, { 0, 1 } };
+// chroma 5x5 diamond taps (dy, dx), each paired with its mirror: (2,0) (1,1) (1,0) (1,-1) (0,2) (0,1) — unrolled in alf_chroma_kernel
 
 // clamp(x, -c, c) in one VALU op (the compiler cannot prove -c <= c, so it would emit max + min)
 __device__ __forceinline__ int clamp_sym(int x, int c)
@@ -45,6 +45,19 @@ __device__ __forceinline__ int clamp_sym(int x, int c)
 __device__ __forceinline__ int mad24(int f, int p, int acc) { return __mul24(f, p) + acc; }
 
 // rows between row y and the virtual boundary on y's own side (0 = adjacent): taps fold to min(k, dist)
+// 8 consecutive samples as four registers of two 16-bit samples each, whatever the storage type
+template <int BD> __device__ __forceinline__ void load8_u16(const typename Px<BD>::type *p, uint32_t (&d)[4])
+{
+    if (BD > 8) {
+        const uint4 q = gld<uint4>(p);
+        d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    } else {
+        const uint2 q = gld<uint2>(p);
+        d[0] = __builtin_amdgcn_perm(0, q.x, 0x0c010c00u); d[1] = __builtin_amdgcn_perm(0, q.x, 0x0c030c02u);
+        d[2] = __builtin_amdgcn_perm(0, q.y, 0x0c010c00u); d[3] = __builtin_amdgcn_perm(0, q.y, 0x0c030c02u);
+    }
+}
+
 __device__ __forceinline__ int vb_dist(int y, int vb_pos) { return y < vb_pos ? vb_pos - 1 - y : y - vb_pos; }
 
 // ---------------------------------------------------------------------------------------------- tile staging
@@ -309,21 +322,34 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
     for (int i = threadIdx.x; i < rows * lpr; i += blockDim.x) {
         const int yl = i / lpr, x = (i - yl * lpr) * 4;
         const int y = y_base + yl, dist = vb_dist(y, vb_pos), tr0 = yl + 3;
+        // 5 rows x 8 columns (x - 2 .. x + 5) of the tile in registers: rows 0 / +-1 / +-2 folded onto the virtual boundary
+        const int d1 = min(1, dist), d2 = min(2, dist);
+        uint32_t win[5][4];
+        {
+            const int rr[5] = { tr0 - d2, tr0 - d1, tr0, tr0 + d1, tr0 + d2 };
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const uint32_t *p = (const uint32_t *)&tile[rr[r]][x + kColOff - 2];       // even index: 4-byte aligned
+#pragma unroll
+                for (int m = 0; m < 4; m++) win[r][m] = p[m];
+            }
+        }
+#define WPX(r, c) ((int)((win[r][(c) >> 1] >> (((c) & 1) * 16)) & 0xffff))
         int out[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int tc0 = x + j + kColOff;
-            const int cur = tile[tr0][tc0];
+            const int cur = WPX(2, j + 2);
             int sum = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const int dy = min((int)kChromaTap[k][0], dist), dx = kChromaTap[k][1];
-                const int a = tile[tr0 + dy][tc0 + dx], b = tile[tr0 - dy][tc0 - dx];
-                sum = mad24(f[k], clamp_sym(a - cur, c[k]) + clamp_sym(b - cur, c[k]), sum);
-            }
+            sum = mad24(f[0], clamp_sym(WPX(4, j + 2) - cur, c[0]) + clamp_sym(WPX(0, j + 2) - cur, c[0]), sum);     // (2, 0)
+            sum = mad24(f[1], clamp_sym(WPX(3, j + 3) - cur, c[1]) + clamp_sym(WPX(1, j + 1) - cur, c[1]), sum);     // (1, 1)
+            sum = mad24(f[2], clamp_sym(WPX(3, j + 2) - cur, c[2]) + clamp_sym(WPX(1, j + 2) - cur, c[2]), sum);     // (1, 0)
+            sum = mad24(f[3], clamp_sym(WPX(3, j + 1) - cur, c[3]) + clamp_sym(WPX(1, j + 3) - cur, c[3]), sum);     // (1, -1)
+            sum = mad24(f[4], clamp_sym(WPX(2, j + 4) - cur, c[4]) + clamp_sym(WPX(2, j) - cur, c[4]), sum);         // (0, 2)
+            sum = mad24(f[5], clamp_sym(WPX(2, j + 3) - cur, c[5]) + clamp_sym(WPX(2, j + 1) - cur, c[5]), sum);     // (0, 1)
             sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
             out[j] = clip_px<BD>(sum + cur);
         }
+#undef WPX
         uint8_t *d = dst + (ptrdiff_t)y * job.dst_stride;
         if (BD > 8)
             gst<uint2>(d + x * 2, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
@@ -346,6 +372,54 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
     int f[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) f[k] = ((const int16_t *)job.coeff)[k];
+    if (hs == 1 && (job.w & 3) == 0) {
+        // 4:2:0 / 4:2:2: a lane corrects 4 consecutive chroma samples; the 8 co-located luma samples of each of the four rows
+        // involved come as one vector (the taps at 2x - 1 / 2x + 1 are the neighbouring halves of its registers), plus the one
+        // sample left of the vector for the two rows that have side taps.  All loads go out before the first use.
+        using px_t = typename Px<BD>::type;
+        const int wq = job.w >> 2;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < wq * job.h; i += gridDim.x * blockDim.x) {
+            const int y = i / wq, x = (i - y * wq) * 4;
+            const int ly = y << vs;
+            if (!vs && (ly == vb_pos || ly == vb_pos + 1))
+                continue;
+            int up = -1, dn = 1, dn2 = 2;
+            if (ly == vb_pos - 2 || ly == vb_pos + 1) dn2 = 1;
+            else if (ly == vb_pos - 1 || ly == vb_pos) up = dn = dn2 = 0;
+            const px_t *l0 = (const px_t *)luma + (ptrdiff_t)ly * ls + 2 * x;
+            uint32_t ru[4], rc[4], rd[4], r2[4];
+            load8_u16<BD>(l0 + up * ls, ru);
+            load8_u16<BD>(l0, rc);
+            load8_u16<BD>(l0 + dn * ls, rd);
+            load8_u16<BD>(l0 + dn2 * ls, r2);
+            const int ec = gld<px_t>(l0 - 1), ed = gld<px_t>(l0 + dn * ls - 1);
+            uint8_t *d = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride + x * (int)sizeof(px_t);
+            uint32_t cv[2];
+            if (BD > 8) { const uint2 q = gld<uint2>(d); cv[0] = q.x; cv[1] = q.y; }
+            else { const uint32_t q = gld<uint32_t>(d); cv[0] = __builtin_amdgcn_perm(0, q, 0x0c010c00u); cv[1] = __builtin_amdgcn_perm(0, q, 0x0c030c02u); }
+            int out[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = rc[j] & 0xffff;
+                const int lc = j ? (int)(rc[j - 1] >> 16) : ec, ld = j ? (int)(rd[j - 1] >> 16) : ed;
+                int sum = 0;
+                sum += f[0] * ((int)(ru[j] & 0xffff) - c);
+                sum += f[1] * (lc - c);
+                sum += f[2] * ((int)(rc[j] >> 16) - c);
+                sum += f[3] * (ld - c);
+                sum += f[4] * ((int)(rd[j] & 0xffff) - c);
+                sum += f[5] * ((int)(rd[j] >> 16) - c);
+                sum += f[6] * ((int)(r2[j] & 0xffff) - c);
+                sum = clip3((sum + 64) >> 7, -(1 << (BD - 1)), (1 << (BD - 1)) - 1);
+                out[j] = clip_px<BD>(sum + (int)((cv[j >> 1] >> ((j & 1) * 16)) & 0xffff));
+            }
+            if (BD > 8)
+                gst<uint2>(d, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
+            else
+                gst<uint32_t>(d, out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24));
+        }
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
         const int y = i / job.w, x = i - y * job.w;
         const int ly = y << vs;
