@@ -40,7 +40,11 @@ def random_blocks(rng, pic_w, pic_h, n_max=10 ** 9):
     while y + 16 <= pic_h:
         x = 0
         while x + 16 <= pic_w:
-            w, h = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
+            if rng.random() < 0.25:
+                # small blocks (no DMVR / BDOF for those in VVC): 4 wide / 4 or 12 high -> chroma 2 wide
+                w, h = int(rng.choice([4, 8, 16])), int(rng.choice([4, 12]))
+            else:
+                w, h = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
             out.append((x, y, w, h))
             x += 16
         y += 16
