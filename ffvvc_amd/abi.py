@@ -111,6 +111,7 @@ BATCH_SIGNATURES = {
     "pred_fused_batch": ("v", "pipi"),
     "bipred_batch":     ("v", "pipi"),
     "bipred_chroma_batch": ("v", "pipi"),
+    "affine_batch":     ("v", "pipi"),
 }
 
 
@@ -231,6 +232,19 @@ class BipredResult(ctypes.Structure):
     """Mirror of vvc355_bipred_result."""
     _fields_ = [("mv", ctypes.c_int32 * 4), ("bdof", ctypes.c_int32), ("min_sad", ctypes.c_int32),
                 ("searched", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class AffineJob(ctypes.Structure):
+    """Mirror of vvc355_affine_job (and of the oracle's orc_affine_job)."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("ref0", ctypes.c_uint64), ("ref1", ctypes.c_uint64), ("diff_mv", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("ref0_stride", ctypes.c_int32), ("ref1_stride", ctypes.c_int32),
+        ("mv", ctypes.c_int32 * 4),
+        ("x", ctypes.c_int16), ("y", ctypes.c_int16), ("pic_w", ctypes.c_int16), ("pic_h", ctypes.c_int16),
+        ("denom", ctypes.c_int16), ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
+        ("pred_flag", ctypes.c_uint8), ("prof0", ctypes.c_uint8), ("prof1", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
+        ("pad_", ctypes.c_uint8 * 6),
+    ]
 
 
 class DequantJob(ctypes.Structure):

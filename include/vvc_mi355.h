@@ -440,6 +440,33 @@ void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev
 /* the same for a launch in which EVERY job has chroma != 0 (jobs that do not are skipped): smaller LDS footprint */
 void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs);
 
+/* ------------------------------------------------------------------ affine sub-blocks with PROF (affine.hip) */
+
+/*
+ * One 4x4 luma sub-block of an affine coding unit, what pred_affine_blk (vvc_inter.c:864-897) does per sub-block through
+ * luma_prof_uni (:369-406) / luma_prof_bi (:408-447): interpolation with the affine filter set
+ * (ff_vvc_inter_luma_filters[2]), edge emulation to the picture by clamped reads, and for the lists whose cb_prof_flag is
+ * set fetch_samples + apply_prof / apply_prof_uni / apply_prof_uni_w; otherwise put_uni / put_uni_w, or avg / w_avg for
+ * bi-prediction.  Chroma of affine blocks is ordinary 4-tap prediction at the averaged motion (vvc_inter.c:884-895): use
+ * vvc355_pred_fused_batch / vvc355_bipred_chroma_batch for it.
+ *   pred_flag   1 = list 0 only, 2 = list 1 only, 3 = both (mvf->pred_flag)
+ *   mv          sub-block motion mv[L0].x, .y, mv[L1].x, .y in 1/16 sample
+ *   prof0/1     pu->cb_prof_flag[L0 / L1]
+ *   diff_mv     DEVICE address of int16 [2 lists][x | y][16]: pu->diff_mv_x[l], pu->diff_mv_y[l] (may be 0 when no list uses PROF)
+ *   weights     uni-prediction: derive_weight_uni -> (denom, w0, o0); bi-prediction: derive_weight -> (denom, w0, w1, o0, o1)
+ */
+typedef struct vvc355_affine_job {
+    uint64_t dst, ref0, ref1, diff_mv;
+    int32_t  dst_stride, ref0_stride, ref1_stride;      /* bytes */
+    int32_t  mv[4];
+    int16_t  x, y, pic_w, pic_h;
+    int16_t  denom, w0, w1, o0, o1;
+    uint8_t  pred_flag, prof0, prof1, weight_flag;
+    uint8_t  pad_[6];
+} vvc355_affine_job;
+
+void vvc355_affine_batch(void *stream, int bd, const vvc355_affine_job *jobs_dev, int n_jobs);
+
 #ifdef __cplusplus
 }
 #endif

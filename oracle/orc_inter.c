@@ -501,3 +501,67 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
     else
         orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h);
 }
+
+
+/* ------------------------------------------------------------------ callers: one 4x4 luma sub-block of an affine CU
+ *
+ * luma_prof_uni (vvc_inter.c:369-406) and luma_prof_bi (:408-447), as pred_affine_blk (:864-897) calls them per sub-block:
+ * the affine filter set (ff_vvc_inter_luma_filters[2]), edge emulation to the picture, and — where cb_prof_flag is set —
+ * put into a temporary, fetch_samples, apply_prof*.  diff_mv = int16 [list][x | y][16] (pu->diff_mv_x / diff_mv_y).
+ */
+ORC_API void orc_affine_block(int bd, const orc_affine_job *job)
+{
+    const int wide = bd > 8;
+    const uint8_t *ref[2] = { (const uint8_t *)(uintptr_t)job->ref0, (const uint8_t *)(uintptr_t)job->ref1 };
+    const ptrdiff_t rstride[2] = { job->ref0_stride, job->ref1_stride };
+    const int16_t *dmv = (const int16_t *)(uintptr_t)job->diff_mv;
+    const int prof[2] = { job->prof0, job->prof1 };
+    uint8_t *dst = (uint8_t *)(uintptr_t)job->dst;
+    static _Thread_local int16_t tmpbuf[3][(8 + 4) * ORC_PB];
+    static _Thread_local uint8_t emu[EMU_STRIDE * 16 * 2];
+    int16_t *tmp[2] = { tmpbuf[0] + 2 * ORC_PB + 32, tmpbuf[1] + 2 * ORC_PB + 32 };
+    int16_t *prof_tmp = tmpbuf[2] + 2 * ORC_PB + 32;                 /* lc->tmp(2) + PROF_TEMP_OFFSET: room for the ring */
+    const int bi = job->pred_flag == 3;
+
+    for (int i = 0; i < 2; i++) {
+        if (!(job->pred_flag & (1 << i)))
+            continue;
+        const int mvx = job->mv[2 * i], mvy = job->mv[2 * i + 1];
+        const int mx = mvx & 15, my = mvy & 15;
+        const int ox = job->x + (mvx >> 4), oy = job->y + (mvy >> 4);
+        const int8_t *hf = orc_tab_inter_luma_filters + (2 * 16 + mx) * 8, *vf = orc_tab_inter_luma_filters + (2 * 16 + my) * 8;
+        emu_window(wide, emu, ref[i], rstride[i], ox - 3, oy - 3, 4 + 7, 4 + 7, 0, 0, job->pic_w - 1, job->pic_h - 1);
+        const uint8_t *src = emu + (((ptrdiff_t)3 * EMU_STRIDE + 3) << wide);
+        const ptrdiff_t ss = (ptrdiff_t)EMU_STRIDE << wide;
+        const int16_t *dmx = dmv + i * 32, *dmy = dmx + 16;
+        if (bi) {
+            if (!prof[i]) {
+                orc_put(bd, 0, !!my, !!mx, tmp[i], src, ss, 4, hf, vf, 4);
+            } else {
+                orc_put(bd, 0, !!my, !!mx, prof_tmp, src, ss, 4, hf, vf, 4);
+                orc_fetch_samples(bd, prof_tmp, src, ss, mx, my);
+                orc_apply_prof(bd, tmp[i], prof_tmp, dmx, dmy);
+            }
+            continue;
+        }
+        /* uni-prediction: weights in (w0, o0) */
+        if (prof[i]) {
+            orc_put(bd, 0, !!my, !!mx, prof_tmp, src, ss, 4, hf, vf, 4);
+            orc_fetch_samples(bd, prof_tmp, src, ss, mx, my);
+            if (!job->weight_flag)
+                orc_apply_prof_uni(bd, dst, job->dst_stride, prof_tmp, dmx, dmy);
+            else
+                orc_apply_prof_uni_w(bd, dst, job->dst_stride, prof_tmp, dmx, dmy, job->denom, job->w0, job->o0);
+        } else if (!job->weight_flag) {
+            orc_put_uni(bd, 0, !!my, !!mx, dst, job->dst_stride, src, ss, 4, hf, vf, 4);
+        } else {
+            orc_put_uni_w(bd, 0, !!my, !!mx, dst, job->dst_stride, src, ss, 4, job->denom, job->w0, job->o0, hf, vf, 4);
+        }
+    }
+    if (bi) {
+        if (job->weight_flag)
+            orc_w_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], 4, 4, job->denom, job->w0, job->w1, job->o0, job->o1);
+        else
+            orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], 4, 4);
+    }
+}

@@ -116,6 +116,19 @@ typedef struct orc_bipred_result {
 } orc_bipred_result;
 void orc_bipred_block(int bd, const orc_bipred_job *job);
 
+/* ---- one 4x4 luma sub-block of an affine coding unit incl. PROF (orc_inter.c, "luma_prof_uni / luma_prof_bi") ----
+ * Same layout as vvc355_affine_job of include/vvc_mi355.h, with host addresses. */
+typedef struct orc_affine_job {
+    uint64_t dst, ref0, ref1, diff_mv;
+    int32_t  dst_stride, ref0_stride, ref1_stride;
+    int32_t  mv[4];
+    int16_t  x, y, pic_w, pic_h;
+    int16_t  denom, w0, w1, o0, o1;
+    uint8_t  pred_flag, prof0, prof1, weight_flag;
+    uint8_t  pad_[6];
+} orc_affine_job;
+void orc_affine_block(int bd, const orc_affine_job *job);
+
 typedef struct orc_intra_job {
     uint64_t plane;
     int32_t  stride;

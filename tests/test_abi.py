@@ -39,3 +39,4 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.AlfJob) == 64
     assert ctypes.sizeof(abi.DequantJob) == 32
     assert ctypes.sizeof(abi.BipredJob) == 96 and ctypes.sizeof(abi.BipredResult) == 32
+    assert ctypes.sizeof(abi.AffineJob) == 88
