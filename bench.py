@@ -31,12 +31,14 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CTB = 128
 # what the chain still lacks of BASELINE.json configs[3] (8K random-access, full in-loop filter chain)
 MISSING = ["intra wavefront ordering (intra TUs are launched as one independent batch)",
-           "PROF / affine and GPM / CIIP blocks in the MC stage (slots exist; the frame mix is regular bi-prediction only)"]
+           "affine (PROF) blocks: batched stage exists (vvc355_affine_batch, bench.py --affine-frac), not part of the metric's frame mix",
+           "GPM / CIIP blocks in the MC stage (slots exist; the frame mix is regular bi-prediction only)"]
 
 TC_TABLE = [0] * 18 + [3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10, 10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45,
                        51, 57, 64, 71, 80, 89, 100, 112, 125, 141, 157, 177, 198, 222, 250, 280, 314, 352, 395]
@@ -119,9 +121,15 @@ def build_chain(lib, torch, fr):
     # with DMVR and BDOF switched on (search, parametric refinement, 8-tap MC at the refined motion, BDOF), then their 8x8
     # chroma blocks (4-tap) at the refined motion.  Motion is random within +-24 samples, so part of the blocks at the picture
     # border exercise the edge emulation; uniformly random references make every DMVR search run to the end (worst case).
+    # optionally (--affine-frac, not part of the metric's workload) some of the inter CTUs are affine instead: 4x4 luma
+    # sub-blocks, bi-predicted with PROF on both lists, chroma at the sub-block motion
+    ctu_affine = ctu_inter & (rng.random(fr.n_ctus) < AFFINE_FRAC)
     bs = 16
     x0, y0 = batch.block_grid(fr.width // bs * bs, fr.height // bs * bs, bs, bs)
-    inter = ctu_inter[(y0 // CTB) * fr.ncx + (x0 // CTB)]
+    ctu_of = (y0 // CTB) * fr.ncx + (x0 // CTB)
+    aff_blk = ctu_affine[ctu_of]
+    inter = ctu_inter[ctu_of] & ~aff_blk
+    xa0, ya0 = x0[aff_blk], y0[aff_blk]
     x0, y0 = x0[inter], y0[inter]
     n_blk = len(x0)
     d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8))
@@ -156,6 +164,48 @@ def build_chain(lib, torch, fr):
 
     chain.append(Stage("inter_pred_bi_dmvr_bdof", f"bipred_kernel<{bd}>", launch_bipred,
                        inter_samples * 3 * isz))            # two reference samples read + one sample written
+
+    if len(xa0):
+        # affine CTUs: every 16x16 area = 16 luma sub-blocks of 4x4 (own motion, PROF on both lists) + its 8x8 chroma blocks
+        sx, sy = np.meshgrid(np.arange(0, 16, 4), np.arange(0, 16, 4))
+        ax = (xa0[:, None] + sx.ravel()[None, :]).ravel()
+        ay = (ya0[:, None] + sy.ravel()[None, :]).ravel()
+        n_sb = len(ax)
+        base_mv = np.repeat(rng.integers(-24 * 16, 24 * 16 + 1, size=(len(xa0), 4)), 16, axis=0)
+        afj = batch.job_array(abi.AffineJob, n_sb)
+        afj["dst"] = ptr(rec[0]) + ay * fr.pitch(rec[0]) + ax * isz
+        afj["dst_stride"] = fr.pitch(rec[0])
+        for r, key in enumerate(("ref0", "ref1")):
+            afj[key] = ptr(ref[r][0]) + Frame.PAD * fr.pitch(ref[r][0]) + Frame.PAD * isz
+            afj[key + "_stride"] = fr.pitch(ref[r][0])
+        d_dmv = fr.upload(rng.integers(-32, 33, size=(2, 2, 16)).astype(np.int16))
+        afj["diff_mv"] = ptr(d_dmv)
+        afj["mv"] = base_mv + rng.integers(-8, 9, size=(n_sb, 4))
+        afj["x"], afj["y"], afj["pic_w"], afj["pic_h"] = ax, ay, fr.width, fr.height
+        afj["pred_flag"], afj["prof0"], afj["prof1"] = 3, 1, 1
+        acj = []
+        for c in (1, 2):
+            j = batch.job_array(abi.BipredJob, len(xa0))
+            j["dst"] = ptr(rec[c]) + (ya0 >> 1) * fr.pitch(rec[c]) + (xa0 >> 1) * isz
+            j["dst_stride"] = fr.pitch(rec[c])
+            for r, key in enumerate(("ref0", "ref1")):
+                j[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz
+                j[key + "_stride"] = fr.pitch(ref[r][c])
+            j["mv"] = base_mv[::16]
+            j["x"], j["y"], j["w"], j["h"] = xa0 >> 1, ya0 >> 1, 8, 8
+            j["pic_w"], j["pic_h"] = fr.dims[c]
+            j["chroma"], j["hs"], j["vs"] = 1, 1, 1
+            acj.append(j)
+        afc = np.empty(2 * len(xa0), dtype=acj[0].dtype)
+        afc[0::2], afc[1::2] = acj[0], acj[1]
+        d_afj, d_afc = fr.upload(afj.view(np.uint8)), fr.upload(afc.view(np.uint8))
+        n_afc = len(afc)
+
+        def launch_affine(st):
+            lib.vvc355_affine_batch(st, bd, ptr(d_afj), n_sb)
+            lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_afc), n_afc)
+
+        chain.append(Stage("inter_pred_affine_prof", f"affine_kernel<{bd}>", launch_affine, len(xa0) * (256 + 128) * 3 * isz))
 
     # ---------------------------------------------------------------- intra prediction of the intra CTUs (16x16 luma, 8x8 chroma TUs)
     ij = []
@@ -489,14 +539,16 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
+    ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
-    global MC_TOOLS
+    global MC_TOOLS, AFFINE_FRAC
     MC_TOOLS = args.mc_tools & 3
+    AFFINE_FRAC = args.affine_frac
     import torch
     import torch.distributed as dist
 
@@ -572,7 +624,7 @@ def main():
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
                             f"(80 % bi-pred inter CTUs, 20 % intra), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only else ["PROFILING RUN: --mc-tools / --only reduce the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC else ["PROFILING RUN: --mc-tools / --only / --affine-frac change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {
