@@ -2,6 +2,8 @@
 Input distributions follow tests/checkasm/vvc_sao.c:51-66,76,113 (offsets < 2^(bd-5), band class 0..31, eo 0..3) and, for
 deblocking (which has no checkasm test in the reference), beta'/tc' of Table 43 for QP 22..50 on smooth-plus-step content
 so that every decision branch (none / weak / strong / long-tap) is reached."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,53 @@ def test_deblock(dev, orc, bd):
         assert la == lb
         hits += int(not np.array_equal(a, img))
     assert hits > 100          # the generator really exercises the filters
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_deblock_frame(dev, orc, bd):
+    """All edges of one direction of a picture in ONE launch (vvc355_deblock_batch) vs the oracle filtering them one after the
+    other: the kernel may only write the samples a filter changes, because neighbouring edges are filtered concurrently.
+    Edge spacing follows what the standard allows: 8 samples apart with filter lengths <= 3, 32 apart for the 5 / 7 tap sides."""
+    import bipred_cases as bc
+    from ffvvc_amd import abi, batch
+    rng = np.random.default_rng(0x5EED0330 + bd)
+    pw, ph = 256, 128
+    isz = 1 if bd == 8 else 2
+    for (dirn, spacing, lens) in [(1, 8, [1, 2, 3]), (0, 8, [1, 2, 3]), (1, 32, [3, 5, 7]), (0, 32, [3, 5, 7])]:
+        base = bc.smooth_picture(rng, ph, pw, bd, scale=32).astype(np.int64)
+        # blocking artefacts: a small random offset per 8x8 block
+        offs = rng.integers(-(1 << (bd - 6)), (1 << (bd - 6)) + 1, size=(ph // 8, pw // 8))
+        pic = np.clip(base + np.kron(offs, np.ones((8, 8), np.int64)), 0, (1 << bd) - 1).astype(np.uint8 if bd == 8 else np.uint16)
+        want = pic.copy()
+        pitched = batch.to_pitched(pic)
+        pitch = pitched.shape[1] * isz
+        d_pic = batch.DeviceBuffer.from_host(pitched)
+        jobs = []
+        along, across = (ph, pw) if dirn == 1 else (pw, ph)          # dir 1: vertical edges (filter along rows)
+        for e in range(spacing, across, spacing):
+            for s in range(0, along, 8):
+                qp = rng.integers(22, 51, size=4)
+                j = abi.DeblockJob()
+                for k in range(4):
+                    j.beta[k], j.tc[k] = BETA[qp[k]], TC[min(qp[k] + 2, 65)]
+                    j.no_p[k], j.no_q[k] = int(rng.integers(0, 8) == 0), int(rng.integers(0, 8) == 0)
+                    j.max_len_p[k], j.max_len_q[k] = int(rng.choice(lens)), int(rng.choice(lens))
+                j.dir, j.chroma, j.flag = dirn, 0, 0
+                x, y = (e, s) if dirn == 1 else (s, e)
+                jobs.append((j, x, y))
+        for (j, x, y) in jobs:
+            orc.orc_lf_filter_luma(bd, dirn, P(want, y * pw + x), pw * isz, ctypes.addressof(j) + abi.DeblockJob.beta.offset,
+                                   ctypes.addressof(j) + abi.DeblockJob.tc.offset, ctypes.addressof(j) + abi.DeblockJob.no_p.offset,
+                                   ctypes.addressof(j) + abi.DeblockJob.no_q.offset, ctypes.addressof(j) + abi.DeblockJob.max_len_p.offset,
+                                   ctypes.addressof(j) + abi.DeblockJob.max_len_q.offset, 0)
+        arr = (abi.DeblockJob * len(jobs))()
+        for i, (j, x, y) in enumerate(jobs):
+            j.pix, j.stride = d_pic.ptr + y * pitch + x * isz, pitch
+            arr[i] = j
+        d_jobs = batch.jobs_to_device(arr)
+        dev.vvc355_deblock_batch(None, bd, d_jobs.ptr, len(jobs))
+        dev.vvc355_stream_sync(None)
+        got = d_pic.to_host(pitched.dtype, pitched.shape)[:, :pw]
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, f"dir={dirn} spacing={spacing} bd={bd}: {len(bad)} samples differ, first at {bad[0].tolist()}"
+        assert np.count_nonzero(want != pic) > 500          # the filters really fired
