@@ -68,3 +68,56 @@ def test_alf_luma_fused_frame(dev, orc, bd, dims):
     assert np.array_equal(got[:, :width], want)
     assert np.all(got[:, width:] == 0x33)      # nothing written outside the picture
     assert ncx >= 1
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_alf_chroma_and_cc_frame(dev, orc, bd):
+    """ALF chroma then CC-ALF of a whole 4:2:0 picture, one launch each over all CTBs, vs the oracle per CTB on edge-replicated
+    copies (vvc_filter.c:1188-1252: alf_filter_chroma, alf_filter_cc)."""
+    from ffvvc_amd import abi
+    rng = np.random.default_rng(0x5EED0180 + bd)
+    cw_, ch_, ctb = 208, 120, 64                      # chroma plane of a 416x240 picture, 64x64 chroma CTBs
+    luma = ac.rand_pixels(rng, (2 * ch_, 2 * cw_), bd)
+    src = ac.rand_pixels(rng, (ch_, cw_), bd)
+    isz = src.itemsize
+    clipv = np.array([1 << bd, 1 << (bd - 3), 1 << (bd - 5), 1 << (bd - 7)], np.int16)
+    filt = [(rng.integers(-64, 64, size=6).astype(np.int16), clipv[rng.integers(0, 4, size=6)].astype(np.int16),
+             np.concatenate([rng.integers(-32, 32, size=7), [0]]).astype(np.int16)) for _ in range(5)]
+    want = src.copy()
+    pad_c = np.pad(src, 8, mode="edge")
+    pad_l = np.pad(luma, 8, mode="edge")
+    pcw, plw = pad_c.shape[1], pad_l.shape[1]
+    ctbs = [(x0, y0, min(ctb, cw_ - x0), min(ctb, ch_ - y0)) for y0 in range(0, ch_, ctb) for x0 in range(0, cw_, ctb)]
+    for i, (x0, y0, w, h) in enumerate(ctbs):
+        f, c, cc = filt[i % len(filt)]
+        orc.orc_alf_filter_chroma(bd, P(want, y0 * cw_ + x0), cw_ * isz, P(pad_c, (y0 + 8) * pcw + x0 + 8), pcw * isz, w, h, P(f), P(c), ctb - 2)
+    for i, (x0, y0, w, h) in enumerate(ctbs):
+        cc = filt[i % len(filt)][2]
+        orc.orc_alf_filter_cc(bd, P(want, y0 * cw_ + x0), cw_ * isz, P(pad_l, (2 * y0 + 8) * plw + 2 * x0 + 8), plw * isz, w, h, 1, 1, P(cc), 2 * ctb - 4)
+
+    p_src, p_luma = batch.to_pitched(src), batch.to_pitched(pad_l)      # CC-ALF reads the luma picture with its apron in place
+    d_src, d_luma = batch.DeviceBuffer.from_host(p_src), batch.DeviceBuffer.from_host(p_luma)
+    d_dst = batch.DeviceBuffer.from_host(np.full_like(p_src, 0x33))
+    pitch, lpitch = p_src.shape[1] * isz, p_luma.shape[1] * isz
+    d_f = [tuple(batch.DeviceBuffer.from_host(a) for a in t) for t in filt]
+    cj, ccj = (abi.AlfJob * len(ctbs))(), (abi.AlfJob * len(ctbs))()
+    for i, (x0, y0, w, h) in enumerate(ctbs):
+        j = cj[i]
+        j.dst, j.src = d_dst.ptr + y0 * pitch + x0 * isz, d_src.ptr + y0 * pitch + x0 * isz
+        j.dst_stride = j.src_stride = pitch
+        j.coeff, j.clip = d_f[i % len(filt)][0].ptr, d_f[i % len(filt)][1].ptr
+        j.w, j.h, j.vb_pos = w, h, ctb - 2
+        j.ext_l, j.ext_t, j.ext_r, j.ext_b = min(2, x0), min(2, y0), min(2, cw_ - x0 - w), min(2, ch_ - y0 - h)
+        k = ccj[i]
+        k.dst, k.dst_stride = j.dst, pitch
+        k.src, k.src_stride = d_luma.ptr + (2 * y0 + 8) * lpitch + (2 * x0 + 8) * isz, lpitch
+        k.coeff = d_f[i % len(filt)][2].ptr
+        k.w, k.h, k.vb_pos, k.hs, k.vs = w, h, 2 * ctb - 4, 1, 1
+    d_cj, d_ccj = batch.jobs_to_device(cj), batch.jobs_to_device(ccj)
+    dev.vvc355_alf_chroma_batch(None, bd, d_cj.ptr, len(ctbs))
+    dev.vvc355_alf_cc_batch(None, bd, d_ccj.ptr, len(ctbs))
+    dev.vvc355_stream_sync(None)
+    got = d_dst.to_host(p_src.dtype, p_src.shape)
+    bad = np.argwhere(got[:, :cw_] != want)
+    assert len(bad) == 0, f"{len(bad)} samples differ, first at {bad[0].tolist()}"
+    assert np.all(got[:, cw_:] == 0x33)

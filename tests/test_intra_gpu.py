@@ -135,3 +135,42 @@ def test_intra_pred_flat(dev, orc, bd):
                                            f"isp={j.isp_split} avail=({j.left_avail},{j.top_avail},{j.cand_up_left})")
         n_cases += int(not np.array_equal(want, plane))
     assert n_cases > 500
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pred_batch_many_jobs(dev, orc, bd):
+    """Many independent blocks in one launch, once per lanes-per-block mapping of the batched entry (half a wave, a wave, a
+    workgroup per block): the blocks sit on a grid with untouched gaps, so each reads only original samples around it."""
+    from ffvvc_amd import batch
+    rng = np.random.default_rng(0x5EED0520 + bd)
+    orc.orc_intra_pred_flat.restype = None
+    orc.orc_intra_pred_flat.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    for (size, lg2_area) in [(8, 6), (16, 8), (32, 10)]:
+        cell = 4 * size
+        pw, ph = 8 * cell, 4 * cell
+        plane = rand_pixels(rng, (ph, pw), bd)
+        want = plane.copy()
+        pitched = batch.to_pitched(plane)
+        pitch = pitched.shape[1] * plane.itemsize
+        d_plane = batch.DeviceBuffer.from_host(pitched)
+        n = (pw // cell) * (ph // cell)
+        arr = (abi.IntraJob * n)()
+        for i in range(n):
+            j = abi.IntraJob()
+            j.x, j.y = (i % (pw // cell)) * cell + size, (i // (pw // cell)) * cell + size
+            j.w = j.h = j.cb_width = j.cb_height = size
+            j.c_idx = int(rng.integers(0, 3))
+            j.mode = int(rng.choice([0, 1, 18, 50] + list(range(2, 67))))
+            j.plane_w, j.plane_h = pw, ph
+            j.left_avail, j.top_avail, j.cand_up_left = 2 * size, 2 * size, 1
+            hj = abi.IntraJob.from_buffer_copy(j)
+            hj.plane, hj.stride = want.ctypes.data, pw * plane.itemsize
+            orc.orc_intra_pred_flat(bd, ctypes.addressof(hj))
+            j.plane, j.stride = d_plane.ptr, pitch
+            arr[i] = j
+        d_jobs = batch.jobs_to_device(arr)
+        dev.vvc355_intra_pred_batch(None, bd, d_jobs.ptr, n, lg2_area)
+        dev.vvc355_stream_sync(None)
+        got = d_plane.to_host(pitched.dtype, pitched.shape)[:, :pw]
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, f"{size}x{size} bd={bd}: {len(bad)} samples differ, first at {bad[0].tolist()}"
