@@ -42,7 +42,14 @@ __device__ __forceinline__ int clamp_sym(int x, int c)
     return r;
 }
 // acc + f * p with 24-bit operands (full-rate v_mad_i32_i24; f is an int16 coefficient, |p| <= 2^(bd+1))
-__device__ __forceinline__ int mad24(int f, int p, int acc) { return __mul24(f, p) + acc; }
+// f * p + acc in one instruction.  Written as __mul24(f, p) + acc the compiler prefers v_mul_i32_i24 + v_add3_u32 (three
+// instructions per two taps instead of two); both operands are far below 24 bits here (|f| <= 2^10, |p| <= 2^13).
+__device__ __forceinline__ int mad24(int f, int p, int acc)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(p), "v"(acc));
+    return r;
+}
 
 // rows between row y and the virtual boundary on y's own side (0 = adjacent): taps fold to min(k, dist)
 // 8 consecutive samples as four registers of two 16-bit samples each, whatever the storage type
