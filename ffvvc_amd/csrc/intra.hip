@@ -82,19 +82,19 @@ template <int NT> __device__ __forceinline__ void group_sync()
 }
 
 template <int BD, int NT, typename R>
-__device__ void pred_planar(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h)
+__device__ void pred_planar(int tid, uint8_t *src, int stride, R top, R left, int w, int h)
 {
     const int lw = ilog2i(w), lh = ilog2i(h);
     for (int i = tid; i < w * h; i += NT) {
         const int y = i >> lw, x = i & (w - 1);           // block sides are powers of two
         const int pv = ((h - 1 - y) * top(x) + (y + 1) * left(h)) << lw;
         const int ph = ((w - 1 - x) * left(y) + (x + 1) * top(w)) << lh;
-        st_px<BD>(src, x + stride * y, (pv + ph + w * h) >> (lw + lh + 1));
+        st_px<BD>(src, x + __mul24(stride, y), (pv + ph + w * h) >> (lw + lh + 1));
     }
 }
 
 template <int BD, int NT, typename R>
-__device__ void pred_dc(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int *scratch)
+__device__ void pred_dc(int tid, uint8_t *src, int stride, R top, R left, int w, int h, int *scratch)
 {
     if (tid == 0) {
         const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
@@ -108,18 +108,18 @@ __device__ void pred_dc(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, 
     const int lw4 = ilog2i(w4);
     for (int i = tid; i < w4 * h; i += NT) {
         const int y = i >> lw4, x = i & (w4 - 1);
-        st_px<BD>(src, x + stride * y, dc);
+        st_px<BD>(src, x + __mul24(stride, y), dc);
     }
 }
 
 template <int BD, int NT, typename R>
-__device__ void pred_vh(int tid, uint8_t *src, ptrdiff_t stride, R ref, int w, int h, bool vertical)
+__device__ void pred_vh(int tid, uint8_t *src, int stride, R ref, int w, int h, bool vertical)
 {
     const int ww = vertical ? w : (w + 3) & ~3;           // pred_h stores whole groups of 4 (:885)
     const int lww = ilog2i(ww);
     for (int i = tid; i < ww * h; i += NT) {
         const int y = i >> lww, x = i & (ww - 1);
-        st_px<BD>(src, x + stride * y, vertical ? ref(x) : ref(y));
+        st_px<BD>(src, x + __mul24(stride, y), vertical ? ref(x) : ref(y));
     }
 }
 
@@ -136,7 +136,7 @@ __device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx,
 }
 
 template <int BD, int NT, typename R>
-__device__ void pred_angular(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, bool vertical,
+__device__ void pred_angular(int tid, uint8_t *src, int stride, R top, R left, int w, int h, bool vertical,
                              int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
 {
     const int angle = intra_pred_angle(mode);
@@ -164,13 +164,13 @@ __device__ void pred_angular(int tid, uint8_t *src, ptrdiff_t stride, R top, R l
                 pred = clip_px<BD>(pred + (((t - pred) * (32 >> min(31, (y * 2) >> nscale)) + 32) >> 6));
             }
         }
-        st_px<BD>(src, x + stride * y, pred);
+        st_px<BD>(src, x + __mul24(stride, y), pred);
     }
 }
 
 // MIP (:708-824).  `red` = 16 ints of LDS scratch.
 template <int BD, int NT, typename R>
-__device__ void pred_mip(int tid, uint8_t *src, ptrdiff_t stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
+__device__ void pred_mip(int tid, uint8_t *src, int stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
 {
     const int size_id = (w == 4 && h == 4) ? 0 : ((w == 4 || h == 4) || (w == 8 && h == 8)) ? 1 : 2;
     const int bsize = size_id == 0 ? 2 : 4, psize = size_id == 2 ? 8 : 4;
@@ -275,10 +275,10 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
     uint16_t (*arr)[kEdgeLen] = arr_all[sub];
     int *scratch = scratch_all[sub];
     const vvc355_intra_job j = jobs[ji];
-    const ptrdiff_t stride = j.stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int stride = j.stride / (int)sizeof(typename Px<BD>::type);      // pixels; int keeps the row offsets full-rate 24-bit multiplies
     const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x % NT;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
-    uint8_t *src = (uint8_t *)j.plane + ((ptrdiff_t)j.y * stride + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
+    uint8_t *src = (uint8_t *)j.plane + (ptrdiff_t)(__mul24(j.y, stride) + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
     const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
     uint16_t *left = arr[0] + kEdgeOrg, *top = arr[1] + kEdgeOrg, *fleft = arr[2] + kEdgeOrg, *ftop = arr[3] + kEdgeOrg;
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
         utop = top_size = refw; uleft = left_size = refh;
     }
     const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
-#define GETP(x, y) ld_px<BD>(src, (ptrdiff_t)(x) + stride * (ptrdiff_t)(y))
+#define GETP(x, y) ld_px<BD>(src, (x) + __mul24(stride, (y)))
     for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
     for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)GETP(i, ref_line);
     group_sync<NT>();
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
                 wl = mode == 50 ? 32 >> min((x << 1) >> scale, 31) : 0;
                 wt = mode == 18 ? 32 >> min((y << 1) >> scale, 31) : 0;
             }
-            st_px<BD>(src, x + stride * y, clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
+            st_px<BD>(src, x + __mul24(stride, y), clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
         }
     }
 #undef GETP

@@ -87,6 +87,20 @@ struct Dequant {
         }
         return clip_intp2((int)((unsigned)c * (unsigned)scale * (unsigned)m + (unsigned)bd_offset) >> bd_shift, range);
     }
+    // the same for |c| < 2^15 (every level a conforming stream codes): c * m and (c * m) * scale are 24-bit multiplies, full
+    // rate instead of two quarter-rate 32-bit multiplies; products wrap to 32 bits exactly like the expression above
+    __device__ __forceinline__ int apply_small(int c, int x, int y) const
+    {
+        if (!on || !c)
+            return c;
+        int m = 16;
+        if (sm) {
+            m = gld<uint8_t>(sm + (((y << lm) >> lh) << lm) + ((x << lm) >> lw));
+            if (dc >= 0 && x == 0 && y == 0)
+                m = dc;
+        }
+        return clip_intp2((int)((unsigned)__mul24(__mul24(c, m), scale) + (unsigned)bd_offset) >> bd_shift, range);
+    }
 };
 
 __device__ __forceinline__ Dequant itx_job_dequant(const vvc355_itx_job &job, int bd)
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
     for (int r = 0; r < 4; r++) {
         praw[r] = make_uint2(0, 0);
         if (act && dst) {
-            const uint8_t *p = dst + (ptrdiff_t)(y0 + r) * job.dst_stride + x0 * (int)sizeof(px_t);
+            const uint8_t *p = dst + row_off(y0 + r, job.dst_stride) + x0 * (int)sizeof(px_t);
             if (BD > 8) praw[r] = gld<uint2>(p);
             else praw[r].x = gld<uint32_t>(p);
         }
@@ -454,8 +468,14 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
         if (need && y0 + r < cntv)
             v = gld<int4>(coeffs + (y0 + r) * W + x0);
         if (dq.on) {
-            v.x = dq.apply(v.x, x0, y0 + r); v.y = dq.apply(v.y, x0 + 1, y0 + r);
-            v.z = dq.apply(v.z, x0 + 2, y0 + r); v.w = dq.apply(v.w, x0 + 3, y0 + r);
+            const unsigned lv = (unsigned)(v.x ^ (v.x >> 31)) | (unsigned)(v.y ^ (v.y >> 31)) | (unsigned)(v.z ^ (v.z >> 31)) | (unsigned)(v.w ^ (v.w >> 31));
+            if ((lv >> 15) == 0) {
+                v.x = dq.apply_small(v.x, x0, y0 + r); v.y = dq.apply_small(v.y, x0 + 1, y0 + r);
+                v.z = dq.apply_small(v.z, x0 + 2, y0 + r); v.w = dq.apply_small(v.w, x0 + 3, y0 + r);
+            } else {
+                v.x = dq.apply(v.x, x0, y0 + r); v.y = dq.apply(v.y, x0 + 1, y0 + r);
+                v.z = dq.apply(v.z, x0 + 2, y0 + r); v.w = dq.apply(v.w, x0 + 3, y0 + r);
+            }
         }
         c[r][0] = x0 + 0 < nzw ? v.x : 0; c[r][1] = x0 + 1 < nzw ? v.y : 0;
         c[r][2] = x0 + 2 < nzw ? v.z : 0; c[r][3] = x0 + 3 < nzw ? v.w : 0;
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
         if (job.store_coeffs)
             gst<int4>(coeffs + (y0 + r) * W + x0, make_int4(res[0], res[1], res[2], res[3]));
         if (dst) {
-            uint8_t *p = dst + (ptrdiff_t)(y0 + r) * job.dst_stride + x0 * (int)sizeof(px_t);
+            uint8_t *p = dst + row_off(y0 + r, job.dst_stride) + x0 * (int)sizeof(px_t);
             if (BD > 8) {
                 const int o0 = clip_px<BD>((int)(praw[r].x & 0xffff) + res[0]), o1 = clip_px<BD>((int)(praw[r].x >> 16) + res[1]);
                 const int o2 = clip_px<BD>((int)(praw[r].y & 0xffff) + res[2]), o3 = clip_px<BD>((int)(praw[r].y >> 16) + res[3]);

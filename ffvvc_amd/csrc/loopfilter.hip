@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void lmcs_kernel(const vvc355_blend_job *__res
     const int wv = vec ? w >> 3 : 0;                          // whole vectors per row
     for (int i = blockIdx.x * 256 + threadIdx.x; i < wv * h; i += gridDim.x * 256) {
         const int y = i / wv, xv = i - y * wv;
-        uint8_t *p = dst + (ptrdiff_t)y * job.dst_stride + xv * VB;
+        uint8_t *p = dst + row_off(y, job.dst_stride) + xv * VB;
         px_t t[8];
         if (BD > 8) { const uint4 q = gld<uint4>(p); __builtin_memcpy(t, &q, sizeof(t)); }
         else { const uint2 q = gld<uint2>(p); __builtin_memcpy(t, &q, sizeof(t)); }
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void lmcs_kernel(const vvc355_blend_job *__res
     const int x_tail = wv * 8, wt = w - x_tail;               // columns left to the per-sample path
     for (int i = blockIdx.x * 256 + threadIdx.x; i < wt * h; i += gridDim.x * 256) {
         const int y = i / wt, x = x_tail + i - y * wt;
-        uint8_t *row = dst + (ptrdiff_t)y * job.dst_stride;
+        uint8_t *row = dst + row_off(y, job.dst_stride);
         st_px<BD>(row, x, lut_lds[ld_px<BD>(row, x)]);
     }
 }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
             continue;
         }
         const int yk = min(max(y0 - 1 + k, ylo), yhi);
-        load8_pk<BD>(src + (ptrdiff_t)yk * ss + x0, v[k]);
+        load8_pk<BD>((const px_t *)((const uint8_t *)src + row_off(yk, job.src_stride)) + x0, v[k]);
     }
     uint32_t out[4][4];
     if (type == 1) {
@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
             if (eo == 1 || ((k == 0 || k == 5) && eo == 0))
                 continue;
             const int yk = min(max(y0 - 1 + k, ylo), yhi);
-            eL[k] = (uint32_t)gld<px_t>(src + (ptrdiff_t)yk * ss + xl);
-            eR[k] = (uint32_t)gld<px_t>(src + (ptrdiff_t)yk * ss + xr);
+            const px_t *rowk = (const px_t *)((const uint8_t *)src + row_off(yk, job.src_stride));
+            eL[k] = (uint32_t)gld<px_t>(rowk + xl);
+            eR[k] = (uint32_t)gld<px_t>(rowk + xr);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
             per_sample_row(y);
             continue;
         }
-        px_t *drow = (px_t *)((uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride);
+        px_t *drow = (px_t *)((uint8_t *)job.dst + row_off(y, job.dst_stride));
         if (x0 + 8 <= w) {
             store8_pk<BD>(drow + x0, out[r]);
         } else {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
 template <int BD> struct Dbk {
     using px_t = typename Px<BD>::type;
     uint8_t *pix;
-    ptrdiff_t xs, ys;
+    int xs, ys;                                  // in pixels; int: offsets stay 32-bit (full-rate 24-bit multiplies)
     int P[4][8], Q[4][8];
     __device__ __forceinline__ int p(int l, int i) const { return P[l][i]; }
     __device__ __forceinline__ int q(int l, int i) const { return Q[l][i]; }
@@ -362,7 +363,7 @@ template <int BD> struct Dbk {
     __device__ __forceinline__ void sq(int l, int i, int v) const { st_px<BD>(pix, l * ys + i * xs, v); }
 
     // n (2 or 4) consecutive samples at pixel offset o
-    __device__ __forceinline__ void vec(ptrdiff_t o, int n, int (&e)[4]) const
+    __device__ __forceinline__ void vec(int o, int n, int (&e)[4]) const
     {
         const px_t *a = (const px_t *)pix + o;
         if (BD > 8) {
@@ -630,14 +631,14 @@ __global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *
     const uint32_t kind = gld<uint32_t>(&jp->dir);             // dir | chroma << 8 | flag << 16
     const int dir = kind & 0xff, chroma = (kind >> 8) & 0xff, flag = (kind >> 16) & 0xff;
     const int lines = chroma ? (flag ? 2 : 4) : 4;
-    const ptrdiff_t pxstride = gld<int32_t>(&jp->stride) / (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const int pxstride = gld<int32_t>(&jp->stride) / (int)sizeof(typename Px<BD>::type);
     uint8_t *pix0 = (uint8_t *)gld<uint64_t>(&jp->pix);
-    const ptrdiff_t xs = dir == 0 ? pxstride : 1, ys = dir == 0 ? 1 : pxstride;
+    const int xs = dir == 0 ? pxstride : 1, ys = dir == 0 ? 1 : pxstride;
     const int seg0 = t & 1;
     if (!chroma) {
         Dbk<BD> d;
         d.xs = xs; d.ys = ys;
-        d.pix = pix0 + seg0 * 4 * ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
+        d.pix = pix0 + (ptrdiff_t)(seg0 * 4 * ys * (int)sizeof(typename Px<BD>::type));
         const int len_p = gld<uint8_t>(&jp->max_len_p[seg0]), len_q = gld<uint8_t>(&jp->max_len_q[seg0]);
         const int far = (len_p > 3 && !flag ? 1 : 0) | (len_q > 3 ? 2 : 0);
         d.load(4, 0, 3);
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *
     for (int seg = seg0; seg < 8 / lines; seg += 2) {
         Dbk<BD> d;
         d.xs = xs; d.ys = ys;
-        d.pix = pix0 + seg * lines * ys * (ptrdiff_t)sizeof(typename Px<BD>::type);
+        d.pix = pix0 + (ptrdiff_t)(seg * lines * ys * (int)sizeof(typename Px<BD>::type));
 #pragma unroll
         for (int l = 0; l < 4; l++)
 #pragma unroll

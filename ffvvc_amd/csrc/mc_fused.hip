@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void pred_fused_kernel(const vvc355_pred_job *
         else if (mode == 1) p = (v0[i] * w0 + v1[i] * w1 + off) >> shift;
         else if (mode == 2) p = (frac & 3) ? (v0[i] + off) >> shift : v0[i] >> (14 - BD);      // integer position = plain copy
         else                p = ((v0[i] * w0 + off) >> shift) + o0 * (1 << (BD - 8));
-        st_px<BD>(dst + (ptrdiff_t)y * dst_stride, x, clip_px<BD>(p));
+        st_px<BD>(dst + row_off(y, dst_stride), x, clip_px<BD>(p));
     }
 }
 
@@ -267,11 +267,11 @@ __device__ __forceinline__ void fetch_clamped(const uint8_t *plane, int stride, 
 {
     using px_t = typename Px<BD>::type;
     const int xa = clip3(wx0 + (lane & 31), rc.x0, rc.x1);
-    const uint8_t *col = plane + (ptrdiff_t)xa * (int)sizeof(px_t);
+    const uint8_t *col = plane + xa * (int)sizeof(px_t);
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int ya = clip3(wy0 + (lane >> 5) + 2 * it, rc.y0, rc.y1);
-        v[it] = (uint16_t)gld<px_t>(col + (ptrdiff_t)ya * stride);
+        v[it] = (uint16_t)gld<px_t>(col + row_off(ya, stride));
     }
 }
 
@@ -295,11 +295,11 @@ template <int BD, int NV>
 __device__ __forceinline__ void fetch_vec4(const uint8_t *plane, int stride, int wx0, int wy0, int nrows, int lane, uint2 (&v)[NV])
 {
     using px_t = typename Px<BD>::type;
-    const uint8_t *org = plane + (ptrdiff_t)wy0 * stride + wx0 * (int)sizeof(px_t);
+    const uint8_t *org = plane + row_off(wy0, stride) + wx0 * (int)sizeof(px_t);
 #pragma unroll
     for (int it = 0; it < NV; it++) {
         const int id = lane + 64 * it, r = min(id / 6, nrows - 1), k = id - (id / 6) * 6;    // rows past the window re-read its last row
-        const uint8_t *p = org + (ptrdiff_t)r * stride + k * 4 * (int)sizeof(px_t);
+        const uint8_t *p = org + row_off(r, stride) + k * 4 * (int)sizeof(px_t);
         if (BD > 8) {
             v[it] = gld<uint2>(p);
         } else {
@@ -566,7 +566,7 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
         const uint8_t *plane = (const uint8_t *)(p ? job->ref1 : job->ref0);
         const int stride = p ? job->ref1_stride : job->ref0_stride;
         const int xa = clip3(ox[p] + x + (fx[p] >> 3), rc[p].x0, rc[p].x1), ya = clip3(oy[p] + y + (fy[p] >> 3), rc[p].y0, rc[p].y1);
-        const int s = gld<px_t>(plane + (ptrdiff_t)ya * stride + xa * (int)sizeof(px_t));
+        const int s = gld<px_t>(plane + row_off(ya, stride) + xa * (int)sizeof(px_t));
         (p ? smp1 : smp0)[(y + 1) * kGs + x + 1] = (int16_t)(s << (14 - BD));
     }
     wave_sync();
@@ -641,7 +641,7 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
     const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
     const int sh = 15 - BD, off = 1 << (sh - 1);
     const int py = by + q;
-    uint8_t *drow = (uint8_t *)job->dst + (ptrdiff_t)py * job->dst_stride;
+    uint8_t *drow = (uint8_t *)job->dst + row_off(py, job->dst_stride);
     int out[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -773,7 +773,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
         if (x >= w || y >= h)
             continue;
         const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
-        st_px<BD>(dst + (ptrdiff_t)y * job->dst_stride, x, clip_px<BD>(p));
+        st_px<BD>(dst + row_off(y, job->dst_stride), x, clip_px<BD>(p));
     }
 }
 
@@ -858,12 +858,12 @@ __global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bi
             const uint8_t *plane = second ? pb : pa;
             const int stride = second ? sb : sa;
             const int xa = clip3(ox[i] - 1 + cc, rc[i].x0, rc[i].x1);
-            const uint8_t *col = plane + (ptrdiff_t)xa * (int)sizeof(px_t);
+            const uint8_t *col = plane + xa * (int)sizeof(px_t);
             const int wy0 = oy[i] - (fy[i] ? 1 : 0);
 #pragma unroll
             for (int it = 0; it < 10; it++) {
                 const int ya = clip3(wy0 + (lane >> 5) + 2 * it, rc[i].y0, rc[i].y1);
-                r[i][it] = (uint16_t)gld<px_t>(col + (ptrdiff_t)ya * stride);
+                r[i][it] = (uint16_t)gld<px_t>(col + row_off(ya, stride));
             }
         }
         store_rows<10>(L.win[0], lane, r[0]);
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bi
         if (xo >= w || y >= h)
             continue;
         const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
-        st_px<BD>(dst + (ptrdiff_t)y * dst_stride, xo, clip_px<BD>(p));
+        st_px<BD>(dst + row_off(y, dst_stride), xo, clip_px<BD>(p));
     }
 }
 
