@@ -112,6 +112,7 @@ BATCH_SIGNATURES = {
     "bipred_batch":     ("v", "pipi"),
     "bipred_chroma_batch": ("v", "pipi"),
     "affine_batch":     ("v", "pipi"),
+    "deblock_frame_pass": ("v", "pipp"),
 }
 
 
@@ -232,6 +233,22 @@ class BipredResult(ctypes.Structure):
     """Mirror of vvc355_bipred_result."""
     _fields_ = [("mv", ctypes.c_int32 * 4), ("bdof", ctypes.c_int32), ("min_sad", ctypes.c_int32),
                 ("searched", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class DeblockFrame(ctypes.Structure):
+    """Mirror of vvc355_deblock_frame (and of the oracle's orc_deblock_frame)."""
+    _fields_ = [
+        ("plane", ctypes.c_uint64 * 3), ("bs", ctypes.c_uint64 * 3),
+        ("max_len_p", ctypes.c_uint64), ("max_len_q", ctypes.c_uint64), ("tb_size_c", ctypes.c_uint64),
+        ("qp_y", ctypes.c_uint64), ("qp_c", ctypes.c_uint64 * 2), ("db_params", ctypes.c_uint64),
+        ("stride", ctypes.c_int32 * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("min_tu_width", ctypes.c_int32), ("min_cb_width", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
+        ("ladf_lower_bound", ctypes.c_int32 * 5),
+        ("min_cb_log2", ctypes.c_uint8), ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8),
+        ("n_comp", ctypes.c_uint8), ("vertical", ctypes.c_uint8), ("qp_bd_offset", ctypes.c_uint8), ("ladf_enabled", ctypes.c_uint8),
+        ("num_ladf_intervals", ctypes.c_uint8), ("ladf_lowest_qp_offset", ctypes.c_int8), ("ladf_qp_offset", ctypes.c_int8 * 4),
+        ("pad_", ctypes.c_uint8 * 6),
+    ]
 
 
 class AffineJob(ctypes.Structure):

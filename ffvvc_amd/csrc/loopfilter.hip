@@ -617,6 +617,35 @@ __device__ __forceinline__ void dbk_chroma_segment(const Dbk<BD> &d, int lines, 
     }
 }
 
+// ---- one segment, everything given: the two kernels below only differ in where the parameters come from
+template <int BD>
+__device__ __forceinline__ void deblock_luma_seg(uint8_t *pix, int xs, int ys, int tc, int beta, int no_p, int no_q, int len_p, int len_q, int flag)
+{
+    Dbk<BD> d;
+    d.xs = xs; d.ys = ys; d.pix = pix;
+    const int far = (len_p > 3 && !flag ? 1 : 0) | (len_q > 3 ? 2 : 0);
+    d.load(4, 0, 3);
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int i = 4; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
+    if (far)
+        d.load(4, 1, far);
+    dbk_luma_segment<BD>(d, tc, beta, no_p, no_q, len_p, len_q, flag);
+}
+template <int BD>
+__device__ __forceinline__ void deblock_chroma_seg(uint8_t *pix, int xs, int ys, int lines, int tc, int beta, int no_p, int no_q, int len_p, int len_q)
+{
+    Dbk<BD> d;
+    d.xs = xs; d.ys = ys; d.pix = pix;
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
+    d.load(lines, 0, 3);
+    dbk_chroma_segment<BD>(d, lines, tc, beta, no_p, no_q, len_p, len_q);
+}
+
 // Two lanes per job; a job is one reference slot call (8 samples along the edge): a lane takes one 4-line segment of a luma or
 // 4-line chroma job, or two of the four 2-line chroma segments.
 template <int BD>
@@ -635,34 +664,111 @@ __global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *
     uint8_t *pix0 = (uint8_t *)gld<uint64_t>(&jp->pix);
     const int xs = dir == 0 ? pxstride : 1, ys = dir == 0 ? 1 : pxstride;
     const int seg0 = t & 1;
+    const int pxb = (int)sizeof(typename Px<BD>::type);
     if (!chroma) {
-        Dbk<BD> d;
-        d.xs = xs; d.ys = ys;
-        d.pix = pix0 + (ptrdiff_t)(seg0 * 4 * ys * (int)sizeof(typename Px<BD>::type));
-        const int len_p = gld<uint8_t>(&jp->max_len_p[seg0]), len_q = gld<uint8_t>(&jp->max_len_q[seg0]);
-        const int far = (len_p > 3 && !flag ? 1 : 0) | (len_q > 3 ? 2 : 0);
-        d.load(4, 0, 3);
-#pragma unroll
-        for (int l = 0; l < 4; l++)
-#pragma unroll
-            for (int i = 4; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
-        if (far)
-            d.load(4, 1, far);
-        dbk_luma_segment<BD>(d, gld<int32_t>(&jp->tc[seg0]), gld<int32_t>(&jp->beta[seg0]), gld<uint8_t>(&jp->no_p[seg0]),
-                             gld<uint8_t>(&jp->no_q[seg0]), len_p, len_q, flag);
+        deblock_luma_seg<BD>(pix0 + (ptrdiff_t)(seg0 * 4 * ys * pxb), xs, ys, gld<int32_t>(&jp->tc[seg0]), gld<int32_t>(&jp->beta[seg0]),
+                             gld<uint8_t>(&jp->no_p[seg0]), gld<uint8_t>(&jp->no_q[seg0]), gld<uint8_t>(&jp->max_len_p[seg0]),
+                             gld<uint8_t>(&jp->max_len_q[seg0]), flag);
         return;
     }
-    for (int seg = seg0; seg < 8 / lines; seg += 2) {
-        Dbk<BD> d;
-        d.xs = xs; d.ys = ys;
-        d.pix = pix0 + (ptrdiff_t)(seg * lines * ys * (int)sizeof(typename Px<BD>::type));
+    for (int seg = seg0; seg < 8 / lines; seg += 2)
+        deblock_chroma_seg<BD>(pix0 + (ptrdiff_t)(seg * lines * ys * pxb), xs, ys, lines, gld<int32_t>(&jp->tc[seg]), gld<int32_t>(&jp->beta[seg]),
+                               gld<uint8_t>(&jp->no_p[seg]), gld<uint8_t>(&jp->no_q[seg]), gld<uint8_t>(&jp->max_len_p[seg]),
+                               gld<uint8_t>(&jp->max_len_q[seg]));
+}
+
+// Table 43 (beta', tc' from Q), vvc_filter.c:38-52
+__device__ static const uint16_t kTcTable[66] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10,
+    10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45, 51, 57, 64, 71, 80, 89, 100, 112, 125, 141, 157, 177, 198, 222, 250, 280, 314,
+    352, 395,
+};
+__device__ static const uint8_t kBetaTable[64] = {
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
+    26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80, 82, 84, 86, 88,
+};
+
+// One deblocking pass of a picture straight from the decoder's side tables (ff_vvc_deblock_vertical / _horizontal,
+// vvc_filter.c:864-1003, per-CTU loop flattened): two lanes per 8-sample unit of an edge, as in deblock_kernel, but each lane
+// looks up its segment's boundary strength and derives QP, beta, tc and the filter lengths itself.  units[c] = first unit of
+// component c, n_along[c] = units along one edge.
+template <int BD>
+__global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock_frame *__restrict__ fp, int u1, int u2, int n_units,
+                                                            int na0, int na1)
+{
+    using px_t = typename Px<BD>::type;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int unit = t >> 1;
+    if (unit >= n_units)
+        return;
+    const vvc355_deblock_frame F = load_uniform(fp);
+    const int vertical = F.vertical;
+    const int c = unit >= u2 ? 2 : unit >= u1 ? 1 : 0;
+    const int local = unit - (c == 2 ? u2 : c == 1 ? u1 : 0);
+    const int n_along = c ? na1 : na0;
+    const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
+    const int grid = c ? (8 << (vertical ? hs : vs)) : 4, step = 8 << (vertical ? vs : hs);
+    const int ke = local / n_along, ku = local - ke * n_along;
+    const int e = (ke + 1) * grid, u = ku * step;                    // edge position across, unit position along (luma units)
+    const int ux = vertical ? e : u, uy = vertical ? u : e;
+    const int hor_ctu_edge = !vertical && !(e & ((1 << F.ctb_log2) - 1));
+    const int ctb = (ux >> F.ctb_log2) + (uy >> F.ctb_log2) * F.ctb_width;
+    const int8_t *dbp = (const int8_t *)F.db_params + ctb * 6;
+    const int beta_offset = gld<int8_t>(dbp + c), tc_offset = gld<int8_t>(dbp + 3 + c);
+    const int shift = vertical ? vs : hs, lines = c ? (shift ? 2 : 4) : 4, nseg = 8 / lines;
+    const uint8_t *bs_tab = (const uint8_t *)F.bs[c];
+    uint8_t *plane = (uint8_t *)F.plane[c];
+    const int stride = F.stride[c], pxstride = stride / (int)sizeof(px_t);
+    const int xs = vertical ? 1 : pxstride, ys = vertical ? pxstride : 1;
+    for (int seg = t & 1; seg < nseg; seg += 2) {
+        const int x = vertical ? e : u + 4 * seg, y = vertical ? u + 4 * seg : e;
+        if (vertical ? y >= F.height : x >= F.width)
+            continue;
+        const int tu = (y >> 2) * F.min_tu_width + (x >> 2);
+        const int bs = gld<uint8_t>(bs_tab + tu);
+        if (!bs)
+            continue;
+        const int xp = x - vertical, yp = y - !vertical;
+        const int tup = (yp >> 2) * F.min_tu_width + (xp >> 2);
+        uint8_t *pix = plane + row_off(y >> vs, stride) + (x >> hs) * (int)sizeof(px_t);
+        int qp, len_p, len_q;
+        if (!c) {
+            const int8_t *qy = (const int8_t *)F.qp_y;
+            const int a = gld<int8_t>(qy + (xp >> F.min_cb_log2) + (yp >> F.min_cb_log2) * F.min_cb_width);
+            const int b = gld<int8_t>(qy + (x >> F.min_cb_log2) + (y >> F.min_cb_log2) * F.min_cb_width);
+            qp = (a + b + 1) >> 1;
+            if (F.ladf_enabled) {
+                // lf.ladf_level (vvc_filter_template.c:788-803) and the interval search of get_qp_y (:840-846)
+                const int level = (ld_px<BD>(pix, -xs) + ld_px<BD>(pix, -xs + 3 * ys) + ld_px<BD>(pix, 0) + ld_px<BD>(pix, 3 * ys)) >> 2;
+                int qp_offset = F.ladf_lowest_qp_offset;
 #pragma unroll
-        for (int l = 0; l < 4; l++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) d.P[l][i] = d.Q[l][i] = 0;
-        d.load(lines, 0, 3);
-        dbk_chroma_segment<BD>(d, lines, gld<int32_t>(&jp->tc[seg]), gld<int32_t>(&jp->beta[seg]), gld<uint8_t>(&jp->no_p[seg]),
-                               gld<uint8_t>(&jp->no_q[seg]), gld<uint8_t>(&jp->max_len_p[seg]), gld<uint8_t>(&jp->max_len_q[seg]));
+                for (int k = 0; k < 4; k++) {
+                    if (k >= F.num_ladf_intervals - 1 || level <= F.ladf_lower_bound[k + 1])
+                        break;
+                    qp_offset = F.ladf_qp_offset[k];
+                }
+                qp += qp_offset;
+            }
+            len_p = gld<uint8_t>((const uint8_t *)F.max_len_p + tu);
+            len_q = gld<uint8_t>((const uint8_t *)F.max_len_q + tu);
+        } else {
+            const int8_t *qc = (const int8_t *)F.qp_c[c - 1];
+            qp = (gld<int8_t>(qc + tup) + gld<int8_t>(qc + tu) - 2 * F.qp_bd_offset + 1) >> 1;
+            const uint8_t *tbs = (const uint8_t *)F.tb_size_c;
+            const int size_p = gld<uint8_t>(tbs + tup), size_q = gld<uint8_t>(tbs + tu);
+            if (size_p >= 8 && size_q >= 8) {
+                len_q = 3;
+                len_p = hor_ctu_edge ? 1 : 3;
+            } else {
+                len_p = len_q = bs == 2;
+            }
+        }
+        const int beta = gld<uint8_t>(kBetaTable + clip3(qp + beta_offset, 0, 63));
+        const int tc = gld<uint16_t>(kTcTable + clip3(qp + 2 * (bs - 1) + (tc_offset & -2), 0, 65));
+        if (!c)
+            deblock_luma_seg<BD>(pix, xs, ys, tc, beta, 0, 0, len_p, len_q, hor_ctu_edge);
+        else
+            deblock_chroma_seg<BD>(pix, xs, ys, lines, tc, beta, 0, 0, len_p, len_q);
     }
 }
 
@@ -730,6 +836,26 @@ void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int 
 void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_h)
 {
     launch_sao_vec(bd, jobs_dev, n_jobs, max_h, (hipStream_t)stream);
+}
+
+void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame *frame_dev, const vvc355_deblock_frame *frame_host)
+{
+    // unit counts per component (the host copy of the descriptor is only read for the geometry)
+    const vvc355_deblock_frame &F = *frame_host;
+    int first[4] = { 0, 0, 0, 0 }, n_along[2] = { 0, 0 };
+    for (int c = 0; c < F.n_comp; c++) {
+        const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
+        const int grid = c ? (8 << (F.vertical ? hs : vs)) : 4, step = 8 << (F.vertical ? vs : hs);
+        const int across = F.vertical ? F.width : F.height, along = F.vertical ? F.height : F.width;
+        const int n_edges = (across - 1) / grid, n_units = (along + step - 1) / step;
+        n_along[c ? 1 : 0] = n_units;
+        first[c + 1] = first[c] + n_edges * n_units;
+    }
+    const int total = first[F.n_comp];
+    if (total <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((deblock_frame_kernel<BD>), dim3((total * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                              frame_dev, first[1], F.n_comp > 2 ? first[2] : total, total, n_along[0], n_along[1]));
+    HIP_CHECK(hipGetLastError());
 }
 
 void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs)

@@ -467,6 +467,38 @@ typedef struct vvc355_affine_job {
 
 void vvc355_affine_batch(void *stream, int bd, const vvc355_affine_job *jobs_dev, int n_jobs);
 
+/* ------------------------------------------------------------------ deblocking stage driver (loopfilter.hip) */
+
+/*
+ * One deblocking pass (all vertical or all horizontal edges) of a whole picture straight from the decoder's side tables:
+ * what ff_vvc_deblock_vertical / ff_vvc_deblock_horizontal (vvc_filter.c:864-1003) do per CTU after vvc_deblock_bs has
+ * filled the boundary-strength tables — edge and 8-sample unit enumeration on the luma 4 / chroma 8 grids, QpY / QpC
+ * averaging incl. the luma-adaptive offset (get_qp_y :830-848, lf.ladf_level), beta / tc from Table 43 with the CTU's
+ * offsets (TC_CALC :823-826), maximum filter lengths (max_filter_length :783-821) and the filter_luma / filter_chroma calls.
+ * No job array: the kernel derives each unit's parameters itself.  The boundary strengths themselves (vvc_deblock_bs,
+ * :308-781: motion, reference and cbf comparisons) are still the caller's.
+ */
+typedef struct vvc355_deblock_frame {
+    uint64_t plane[3];            /* component planes, filtered in place */
+    uint64_t bs[3];               /* this pass's boundary strengths: fc->tab.vertical_bs[c] or horizontal_bs[c], uint8 per 4x4 luma unit */
+    uint64_t max_len_p, max_len_q;/* luma: fc->tab.vertical_p / _q or horizontal_p / _q, uint8 per 4x4 luma unit */
+    uint64_t tb_size_c;           /* chroma: fc->tab.tb_width[CHROMA] (vertical pass) or tb_height[CHROMA], uint8 per 4x4 luma unit */
+    uint64_t qp_y;                /* fc->tab.qp[LUMA], int8 per minimum coding block */
+    uint64_t qp_c[2];             /* fc->tab.qp[CB], [CR], int8 per 4x4 luma unit */
+    uint64_t db_params;           /* fc->tab.deblock: int8 [ctb][6] = beta_offset[3], tc_offset[3] (DBParams, vvc_ps.h:89-92) */
+    int32_t  stride[3];           /* bytes */
+    int32_t  width, height;       /* luma picture size */
+    int32_t  min_tu_width, min_cb_width, ctb_width;
+    int32_t  ladf_lower_bound[5]; /* sps->ladf_interval_lower_bound */
+    uint8_t  min_cb_log2, ctb_log2, hs, vs, n_comp, vertical, qp_bd_offset, ladf_enabled;
+    uint8_t  num_ladf_intervals;
+    int8_t   ladf_lowest_qp_offset, ladf_qp_offset[4];
+    uint8_t  pad_[6];
+} vvc355_deblock_frame;
+
+/* frame_dev: DEVICE address of one descriptor; the launch covers every edge unit of the pass */
+void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame *frame_dev, const vvc355_deblock_frame *frame_host);
+
 #ifdef __cplusplus
 }
 #endif

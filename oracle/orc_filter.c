@@ -675,3 +675,97 @@ ORC_API int orc_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t str
     const ptrdiff_t xs = (dir == 0 ? stride : px) >> wide, ys = (dir == 0 ? px : stride) >> wide;
     return (orc_ld(pix, -xs, wide) + orc_ld(pix, -xs + 3 * ys, wide) + orc_ld(pix, 0, wide) + orc_ld(pix, 3 * ys, wide)) >> 2;
 }
+
+
+/* ------------------------------------------------------------------ callers: one deblocking pass of a picture
+ *
+ * ff_vvc_deblock_vertical (vvc_filter.c:864-932) / ff_vvc_deblock_horizontal (:934-1003) with the per-CTU loop flattened to the
+ * picture: for every component, every edge position on its grid and every 8-sample unit along it, the four (two for luma)
+ * boundary strengths are read; where one is set the unit's QP (get_qp :850-855), beta (betatable), tc (TC_CALC :823-826) and
+ * the maximum filter lengths (max_filter_length :814-821) follow, then the lf.filter_* slot runs.
+ */
+static const uint16_t orc_tctable[66] = {       /* Table 43, vvc_filter.c:38 */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10,
+    10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45, 51, 57, 64, 71, 80, 89, 100, 112, 125, 141, 157, 177, 198, 222, 250, 280, 314,
+    352, 395,
+};
+static const uint8_t orc_betatable[64] = {      /* Table 43, vvc_filter.c:47 */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
+    26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80, 82, 84, 86, 88,
+};
+
+ORC_API void orc_deblock_frame_pass(int bd, const orc_deblock_frame *f)
+{
+    const int wide = bd > 8, vertical = f->vertical;
+    const uint8_t no_pq[4] = { 0, 0, 0, 0 };
+    const int8_t *dbp = (const int8_t *)(uintptr_t)f->db_params;
+    const int8_t *qp_y = (const int8_t *)(uintptr_t)f->qp_y;
+    const uint8_t *len_p = (const uint8_t *)(uintptr_t)f->max_len_p, *len_q = (const uint8_t *)(uintptr_t)f->max_len_q;
+    const uint8_t *tbs = (const uint8_t *)(uintptr_t)f->tb_size_c;
+#define TU(t, x, y) (t)[((y) >> 2) * f->min_tu_width + ((x) >> 2)]
+    for (int c = 0; c < f->n_comp; c++) {
+        const int hs = c ? f->hs : 0, vs = c ? f->vs : 0;
+        uint8_t *plane = (uint8_t *)(uintptr_t)f->plane[c];
+        const uint8_t *bs_tab = (const uint8_t *)(uintptr_t)f->bs[c];
+        const int8_t *qp_c = c ? (const int8_t *)(uintptr_t)f->qp_c[c - 1] : NULL;
+        /* across the edges: grid; along them: units of 8 samples of this component */
+        const int grid = c ? (8 << (vertical ? hs : vs)) : 4;
+        const int step = 8 << (vertical ? vs : hs);
+        const int across_end = vertical ? f->width : f->height, along_end = vertical ? f->height : f->width;
+        const int nseg = 8 >> (2 - (vertical ? vs : hs));
+        for (int e = grid; e < across_end; e += grid)
+            for (int u = 0; u < along_end; u += step) {
+                int32_t bs[4], beta[4] = { 0, 0, 0, 0 }, tc[4];
+                uint8_t max_len_p[4] = { 0, 0, 0, 0 }, max_len_q[4] = { 0, 0, 0, 0 };
+                int any = 0;
+                const int ux = vertical ? e : u, uy = vertical ? u : e;
+                const int hor_ctu_edge = !vertical && !(e % (1 << f->ctb_log2));
+                const int ctb = (ux >> f->ctb_log2) + (uy >> f->ctb_log2) * f->ctb_width;
+                const int beta_offset = dbp[ctb * 6 + c], tc_offset = dbp[ctb * 6 + 3 + c];
+                for (int i = 0; i < nseg; i++) {
+                    const int x = vertical ? e : u + 4 * i, y = vertical ? u + 4 * i : e;
+                    int qp = 0;
+                    bs[i] = (vertical ? y < f->height : x < f->width) ? TU(bs_tab, x, y) : 0;
+                    if (bs[i]) {
+                        const int xp = x - vertical, yp = y - !vertical;
+                        if (!c) {
+                            const int a = qp_y[(xp >> f->min_cb_log2) + (yp >> f->min_cb_log2) * f->min_cb_width];
+                            const int b = qp_y[(x >> f->min_cb_log2) + (y >> f->min_cb_log2) * f->min_cb_width];
+                            qp = (a + b + 1) >> 1;
+                            if (f->ladf_enabled) {
+                                const uint8_t *src = plane + (ptrdiff_t)y * f->stride[0] + ((ptrdiff_t)x << wide);
+                                const int level = orc_lf_ladf_level(bd, vertical, src, f->stride[0]);
+                                int qp_offset = f->ladf_lowest_qp_offset;
+                                for (int k = 0; k < f->num_ladf_intervals - 1 && level > f->ladf_lower_bound[k + 1]; k++)
+                                    qp_offset = f->ladf_qp_offset[k];
+                                qp += qp_offset;
+                            }
+                            max_len_p[i] = TU(len_p, x, y);
+                            max_len_q[i] = TU(len_q, x, y);
+                        } else {
+                            qp = (TU(qp_c, xp, yp) + TU(qp_c, x, y) - 2 * f->qp_bd_offset + 1) >> 1;
+                            const int size_p = TU(tbs, xp, yp), size_q = TU(tbs, x, y);
+                            if (size_p >= 8 && size_q >= 8) {
+                                max_len_p[i] = max_len_q[i] = 3;
+                                if (hor_ctu_edge)
+                                    max_len_p[i] = 1;
+                            } else {
+                                max_len_p[i] = max_len_q[i] = bs[i] == 2;
+                            }
+                        }
+                        beta[i] = orc_betatable[orc_clip3(qp + beta_offset, 0, 63)];
+                        any = 1;
+                    }
+                    tc[i] = bs[i] ? orc_tctable[orc_clip3(qp + 2 * (bs[i] - 1) + (tc_offset & -2), 0, 65)] : 0;
+                }
+                if (!any)
+                    continue;
+                uint8_t *src = plane + (ptrdiff_t)(uy >> vs) * f->stride[c] + ((ptrdiff_t)(ux >> hs) << wide);
+                if (!c)
+                    orc_lf_filter_luma(bd, vertical, src, f->stride[0], beta, tc, no_pq, no_pq, max_len_p, max_len_q, hor_ctu_edge);
+                else
+                    orc_lf_filter_chroma(bd, vertical, src, f->stride[c], beta, tc, no_pq, no_pq, max_len_p, max_len_q, vertical ? vs : hs);
+            }
+    }
+#undef TU
+}

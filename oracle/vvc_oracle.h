@@ -129,6 +129,27 @@ typedef struct orc_affine_job {
 } orc_affine_job;
 void orc_affine_block(int bd, const orc_affine_job *job);
 
+/* ---- one deblocking pass of a picture from the decoder's side tables (orc_filter.c, "ff_vvc_deblock_vertical/horizontal") ----
+ * Same layout as vvc355_deblock_frame of include/vvc_mi355.h, with host addresses. */
+typedef struct orc_deblock_frame {
+    uint64_t plane[3];            /* component planes, filtered in place */
+    uint64_t bs[3];               /* this pass's boundary strengths: fc->tab.vertical_bs[c] or horizontal_bs[c], uint8 per 4x4 luma unit */
+    uint64_t max_len_p, max_len_q;/* luma: fc->tab.vertical_p / _q or horizontal_p / _q, uint8 per 4x4 luma unit */
+    uint64_t tb_size_c;           /* chroma: fc->tab.tb_width[CHROMA] (vertical pass) or tb_height[CHROMA], uint8 per 4x4 luma unit */
+    uint64_t qp_y;                /* fc->tab.qp[LUMA], int8 per minimum coding block */
+    uint64_t qp_c[2];             /* fc->tab.qp[CB], [CR], int8 per 4x4 luma unit */
+    uint64_t db_params;           /* fc->tab.deblock: int8 [ctb][6] = beta_offset[3], tc_offset[3] (DBParams, vvc_ps.h:89-92) */
+    int32_t  stride[3];           /* bytes */
+    int32_t  width, height;       /* luma picture size */
+    int32_t  min_tu_width, min_cb_width, ctb_width;
+    int32_t  ladf_lower_bound[5]; /* sps->ladf_interval_lower_bound */
+    uint8_t  min_cb_log2, ctb_log2, hs, vs, n_comp, vertical, qp_bd_offset, ladf_enabled;
+    uint8_t  num_ladf_intervals;
+    int8_t   ladf_lowest_qp_offset, ladf_qp_offset[4];
+    uint8_t  pad_[6];
+} orc_deblock_frame;
+void orc_deblock_frame_pass(int bd, const orc_deblock_frame *f);
+
 typedef struct orc_intra_job {
     uint64_t plane;
     int32_t  stride;
