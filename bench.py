@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+DEBLOCK_JOBS = True            # --deblock-tables switches to the stage driver that derives every edge's parameters from side tables
 AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -331,12 +332,52 @@ def build_chain(lib, torch, fr):
         return np.concatenate(js)
 
     frame_bytes = sum(w * h for (w, h) in fr.dims) * isz
+
+    def deblock_tables(vertical):
+        """The side tables one pass of the stage driver reads (vvc355_deblock_frame): transform edges every 8 luma samples
+        (every 16 for chroma = its 8-sample grid), boundary strength 1 or 2 on 60 % of the 4-sample segments, filter lengths
+        1..3, QP 22..42, per-CTU beta / tc offsets, LADF on."""
+        tw, th = fr.width // 4, fr.height // 4
+        f = abi.DeblockFrame()
+        pos = (np.arange(tw) * 4)[None, :] if vertical else (np.arange(th) * 4)[:, None]
+        tabs = []
+        for c in range(3):
+            on_edge = (pos % (16 if c else 8) == 0) & (pos > 0)
+            bs = np.where(on_edge & (rng.random((th, tw)) < 0.6), rng.integers(1, 3, size=(th, tw)), 0).astype(np.uint8)
+            tabs.append(fr.upload(bs))
+            f.plane[c], f.stride[c], f.bs[c] = ptr(rec[c]), fr.pitch(rec[c]), ptr(tabs[-1])
+        for key in ("max_len_p", "max_len_q"):
+            tabs.append(fr.upload(rng.choice([1, 2, 3], size=(th, tw)).astype(np.uint8)))
+            setattr(f, key, ptr(tabs[-1]))
+        tabs.append(fr.upload(rng.choice([4, 8, 16], size=(th, tw)).astype(np.uint8)))
+        f.tb_size_c = ptr(tabs[-1])
+        tabs.append(fr.upload(rng.integers(22, 43, size=(fr.height // 8, fr.width // 8)).astype(np.int8)))
+        f.qp_y = ptr(tabs[-1])
+        for k in range(2):
+            tabs.append(fr.upload(rng.integers(22, 43, size=(th, tw)).astype(np.int8) + 6 * (bd - 8)))
+            f.qp_c[k] = ptr(tabs[-1])
+        tabs.append(fr.upload(rng.integers(-6, 7, size=(fr.n_ctus, 6)).astype(np.int8)))
+        f.db_params = ptr(tabs[-1])
+        f.width, f.height, f.min_tu_width, f.min_cb_width, f.ctb_width = fr.width, fr.height, tw, fr.width // 8, fr.ncx
+        f.min_cb_log2, f.ctb_log2, f.hs, f.vs, f.n_comp, f.vertical, f.qp_bd_offset = 3, 7, 1, 1, 3, vertical, 6 * (bd - 8)
+        f.ladf_enabled, f.num_ladf_intervals, f.ladf_lowest_qp_offset = 1, 3, -2
+        f.ladf_qp_offset[0], f.ladf_qp_offset[1] = 1, 3
+        f.ladf_lower_bound[1], f.ladf_lower_bound[2] = 1 << (bd - 2), 1 << (bd - 1)
+        return f, fr.upload(np.frombuffer(bytes(f), np.uint8))
+
     for direction, name in ((1, "deblock_vertical"), (0, "deblock_horizontal")):
-        dj = deblock_jobs(direction)
-        d_dj = fr.upload(dj.view(np.uint8))
-        n_dj = len(dj)
-        chain.append(Stage(name, f"deblock_kernel<{bd}>", (lambda p, n: (lambda st: lib.vvc355_deblock_batch(st, bd, p, n)))(ptr(d_dj), n_dj),
-                           frame_bytes * 2))
+        if DEBLOCK_JOBS:
+            dj = deblock_jobs(direction)
+            d_dj = fr.upload(dj.view(np.uint8))
+            n_dj = len(dj)
+            chain.append(Stage(name, f"deblock_kernel<{bd}>", (lambda p, n: (lambda st: lib.vvc355_deblock_batch(st, bd, p, n)))(ptr(d_dj), n_dj),
+                               frame_bytes * 2))
+        else:
+            hf, d_f = deblock_tables(direction)
+            fr.keep.append(hf)
+            chain.append(Stage(name, f"deblock_frame_kernel<{bd}>",
+                               (lambda p, hp: (lambda st: lib.vvc355_deblock_frame_pass(st, bd, p, hp)))(ptr(d_f), ctypes.addressof(hf)),
+                               frame_bytes * 2))
 
     # ---------------------------------------------------------------- SAO: edge (+ restore at picture borders) or band per CTB
     sj = []
@@ -539,6 +580,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
+    ap.add_argument("--deblock-tables", action="store_true",
+                    help="profiling aid: deblock through vvc355_deblock_frame_pass (parameters derived on the device from side tables)")
     ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     return ap.parse_args()
@@ -546,7 +589,8 @@ def parse_args():
 
 def main():
     args = parse_args()
-    global MC_TOOLS, AFFINE_FRAC
+    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS
+    DEBLOCK_JOBS = not args.deblock_tables
     MC_TOOLS = args.mc_tools & 3
     AFFINE_FRAC = args.affine_frac
     import torch
@@ -624,7 +668,7 @@ def main():
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
                             f"(80 % bi-pred inter CTUs, 20 % intra), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC else ["PROFILING RUN: --mc-tools / --only / --affine-frac change the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and DEBLOCK_JOBS else ["PROFILING RUN: --mc-tools / --only / --affine-frac / --deblock-tables change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {

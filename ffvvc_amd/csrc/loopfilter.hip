@@ -694,7 +694,7 @@ __device__ static const uint8_t kBetaTable[64] = {
 // component c, n_along[c] = units along one edge.
 template <int BD>
 __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock_frame *__restrict__ fp, int u1, int u2, int n_units,
-                                                            int na0, int na1)
+                                                            int na0, int na1, int ne0, int ne1)
 {
     using px_t = typename Px<BD>::type;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -708,13 +708,17 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
     const int n_along = c ? na1 : na0;
     const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
     const int grid = c ? (8 << (vertical ? hs : vs)) : 4, step = 8 << (vertical ? vs : hs);
-    const int ke = local / n_along, ku = local - ke * n_along;
+    // consecutive lanes walk along the rows of the picture: across the edges for the vertical pass, along the edge for the
+    // horizontal one (n_along = units along one edge, n_edges = edges)
+    const int n_edges = c ? ne1 : ne0;
+    int ke, ku;
+    if (vertical) { ku = local / n_edges; ke = local - ku * n_edges; }
+    else          { ke = local / n_along; ku = local - ke * n_along; }
     const int e = (ke + 1) * grid, u = ku * step;                    // edge position across, unit position along (luma units)
     const int ux = vertical ? e : u, uy = vertical ? u : e;
     const int hor_ctu_edge = !vertical && !(e & ((1 << F.ctb_log2) - 1));
     const int ctb = (ux >> F.ctb_log2) + (uy >> F.ctb_log2) * F.ctb_width;
     const int8_t *dbp = (const int8_t *)F.db_params + ctb * 6;
-    const int beta_offset = gld<int8_t>(dbp + c), tc_offset = gld<int8_t>(dbp + 3 + c);
     const int shift = vertical ? vs : hs, lines = c ? (shift ? 2 : 4) : 4, nseg = 8 / lines;
     const uint8_t *bs_tab = (const uint8_t *)F.bs[c];
     uint8_t *plane = (uint8_t *)F.plane[c];
@@ -763,6 +767,7 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
                 len_p = len_q = bs == 2;
             }
         }
+        const int beta_offset = gld<int8_t>(dbp + c), tc_offset = gld<int8_t>(dbp + 3 + c);
         const int beta = gld<uint8_t>(kBetaTable + clip3(qp + beta_offset, 0, 63));
         const int tc = gld<uint16_t>(kTcTable + clip3(qp + 2 * (bs - 1) + (tc_offset & -2), 0, 65));
         if (!c)
@@ -842,19 +847,20 @@ void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame 
 {
     // unit counts per component (the host copy of the descriptor is only read for the geometry)
     const vvc355_deblock_frame &F = *frame_host;
-    int first[4] = { 0, 0, 0, 0 }, n_along[2] = { 0, 0 };
+    int first[4] = { 0, 0, 0, 0 }, n_along[2] = { 0, 0 }, n_edge[2] = { 0, 0 };
     for (int c = 0; c < F.n_comp; c++) {
         const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
         const int grid = c ? (8 << (F.vertical ? hs : vs)) : 4, step = 8 << (F.vertical ? vs : hs);
         const int across = F.vertical ? F.width : F.height, along = F.vertical ? F.height : F.width;
         const int n_edges = (across - 1) / grid, n_units = (along + step - 1) / step;
         n_along[c ? 1 : 0] = n_units;
+        n_edge[c ? 1 : 0] = n_edges;
         first[c + 1] = first[c] + n_edges * n_units;
     }
     const int total = first[F.n_comp];
     if (total <= 0) return;
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((deblock_frame_kernel<BD>), dim3((total * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                                              frame_dev, first[1], F.n_comp > 2 ? first[2] : total, total, n_along[0], n_along[1]));
+                                              frame_dev, first[1], F.n_comp > 2 ? first[2] : total, total, n_along[0], n_along[1], n_edge[0], n_edge[1]));
     HIP_CHECK(hipGetLastError());
 }
 
