@@ -225,7 +225,7 @@ class BipredJob(ctypes.Structure):
         ("denom", ctypes.c_int16), ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
         ("chroma", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("dmvr", ctypes.c_uint8),
         ("bdof", ctypes.c_uint8), ("hf_idx", ctypes.c_uint8), ("vf_idx", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
-        ("pad_", ctypes.c_uint8 * 6),
+        ("pred_flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 5),
     ]
 
 

@@ -656,28 +656,34 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
 }
 
 // both references at motion mv: windows through clamped coordinates, then the separable interpolation of interp_block
+// both = false: uni-prediction — only the first reference (the caller put the list in use at index 0 of every array and in pa / sa)
 template <int BD, int NTAP>
 __device__ __forceinline__ void predict_clamped(const vvc355_bipred_job *job, BipredLds &L, int lane, int lw, int h,
                                                 const int (&ox)[2], const int (&oy)[2], const int (&fx)[2], const int (&fy)[2],
-                                                const ClampRect (&rc)[2], int (&v0)[4], int (&v1)[4])
+                                                const ClampRect (&rc)[2], int (&v0)[4], int (&v1)[4],
+                                                const uint8_t *pa, int sa, const uint8_t *pb, int sb, bool both)
 {
     constexpr int LEAD = NTAP == 8 ? 3 : 1, NIT = (16 + NTAP) / 2;
     {
         const int ax = ox[0] - LEAD, ay = oy[0] - (fy[0] ? LEAD : 0), an = fy[0] ? h + NTAP - 1 : h;
         const int bx = ox[1] - LEAD, by = oy[1] - (fy[1] ? LEAD : 0), bn = fy[1] ? h + NTAP - 1 : h;
-        if (rect_holds(rc[0], ax, ay, an) && rect_holds(rc[1], bx, by, bn)) {
+        if (rect_holds(rc[0], ax, ay, an) && (!both || rect_holds(rc[1], bx, by, bn))) {
             constexpr int NV = NTAP == 8 ? 3 : 2;            // 23 x 6 = 138 <= 192 (luma), 19 x 6 = 114 <= 128 (chroma, h <= 16)
             uint2 q0[NV], q1[NV];
-            fetch_vec4<BD, NV>((const uint8_t *)job->ref0, job->ref0_stride, ax, ay, an, lane, q0);
-            fetch_vec4<BD, NV>((const uint8_t *)job->ref1, job->ref1_stride, bx, by, bn, lane, q1);
+            fetch_vec4<BD, NV>(pa, sa, ax, ay, an, lane, q0);
+            if (both)
+                fetch_vec4<BD, NV>(pb, sb, bx, by, bn, lane, q1);
             put_vec4<NV>(L.win[0], an, lane, q0);
-            put_vec4<NV>(L.win[1], bn, lane, q1);
+            if (both)
+                put_vec4<NV>(L.win[1], bn, lane, q1);
         } else {
             uint16_t r0[NIT], r1[NIT];
-            fetch_clamped<BD, NIT>((const uint8_t *)job->ref0, job->ref0_stride, rc[0], ax, ay, lane, r0);
-            fetch_clamped<BD, NIT>((const uint8_t *)job->ref1, job->ref1_stride, rc[1], bx, by, lane, r1);
+            fetch_clamped<BD, NIT>(pa, sa, rc[0], ax, ay, lane, r0);
+            if (both)
+                fetch_clamped<BD, NIT>(pb, sb, rc[1], bx, by, lane, r1);
             store_rows<NIT>(L.win[0], lane, r0);
-            store_rows<NIT>(L.win[1], lane, r1);
+            if (both)
+                store_rows<NIT>(L.win[1], lane, r1);
         }
         wave_sync();
     }
@@ -694,7 +700,12 @@ __device__ __forceinline__ void predict_clamped(const vvc355_bipred_job *job, Bi
         }
     }
     interp_block<BD, NTAP>(lw, h, fx[0] != 0, fy[0] != 0, t[0][0], t[0][1], t[0][2], t[0][3], L.win[0], L.tmpT, lane, v0);
-    interp_block<BD, NTAP>(lw, h, fx[1] != 0, fy[1] != 0, t[1][0], t[1][1], t[1][2], t[1][3], L.win[1], L.tmpT, lane, v1);
+    if (both)
+        interp_block<BD, NTAP>(lw, h, fx[1] != 0, fy[1] != 0, t[1][0], t[1][1], t[1][2], t[1][3], L.win[1], L.tmpT, lane, v1);
+    else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v1[i] = 0;
+    }
 }
 
 // the window / intermediate part of BipredLds only: what a launch of chroma jobs needs (more waves per CU)
@@ -708,11 +719,12 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
 {
     if (!TOOLS && !job->chroma)
         return;                                          // contract: a chroma-only launch holds chroma jobs
-    const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr;
+    const int uni = job->pred_flag == 1 || job->pred_flag == 2;        // luma_mc_uni / chroma_mc_uni: one list, no DMVR / BDOF
+    const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr && !uni;
     const int lw = 31 - __builtin_clz(w);
     vvc355_bipred_result *rec = (vvc355_bipred_result *)job->rec;
     int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
-    int bdof = TOOLS && !chroma && job->bdof;
+    int bdof = TOOLS && !chroma && job->bdof && !uni;
     if (chroma && rec) {
 #pragma unroll
         for (int k = 0; k < 4; k++) mv[k] = gld<int>(&rec->mv[k]);
@@ -751,10 +763,31 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
         }
     }
     int v0[4], v1[4];
+    const uint8_t *pa = (const uint8_t *)job->ref0, *pb = (const uint8_t *)job->ref1;
+    int sa = job->ref0_stride, sb = job->ref1_stride;
+    if (uni && job->pred_flag == 2) {                     // list 1 only: it takes the first slot
+        pa = pb; sa = sb;
+        ox[0] = ox[1]; oy[0] = oy[1]; fx[0] = fx[1]; fy[0] = fy[1]; rc[0] = rc[1];
+    }
     if (chroma)
-        predict_clamped<BD, 4>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1);
+        predict_clamped<BD, 4>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1, pa, sa, pb, sb, !uni);
     else
-        predict_clamped<BD, 8>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1);
+        predict_clamped<BD, 8>(job, L, lane, lw, h, ox, oy, fx, fy, rc, v0, v1, pa, sa, pb, sb, !uni);
+    if (uni) {
+        // put_uni / put_uni_w (h2656_inter_template.c:44-81): rounding to pixels, weights from derive_weight_uni in (denom, w0, o0)
+        const int wfu = job->weight_flag, sh = (wfu ? job->denom : 0) + 14 - BD, rnd = 1 << (sh - 1);
+        const int xu = lane & 15;
+        uint8_t *dstu = (uint8_t *)job->dst;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+            if (xu >= w || y >= h)
+                continue;
+            const int p = wfu ? ((v0[i] * job->w0 + rnd) >> sh) + job->o0 * (1 << (BD - 8)) : (v0[i] + rnd) >> sh;
+            st_px<BD>(dstu + row_off(y, job->dst_stride), xu, clip_px<BD>(p));
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) { v0[i] = (int16_t)v0[i]; v1[i] = (int16_t)v1[i]; }     // put[..] stores int16
     if (TOOLS && bdof) {
@@ -807,7 +840,8 @@ __global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bi
     const bool has_b = ia + 1 < n_jobs;
     const vvc355_bipred_job ja = load_uniform(jobs + ia), jb = load_uniform(jobs + (has_b ? ia + 1 : ia));
     BipredLds &L = *(BipredLds *)&lds_all[wave];
-    bool pair = has_b && ja.chroma && jb.chroma && ja.w <= 8 && ja.w == jb.w && ja.h == jb.h && ja.x == jb.x && ja.y == jb.y &&
+    const bool bi_a = !(ja.pred_flag == 1 || ja.pred_flag == 2), bi_b = !(jb.pred_flag == 1 || jb.pred_flag == 2);
+    bool pair = has_b && bi_a && bi_b && ja.chroma && jb.chroma && ja.w <= 8 && ja.w == jb.w && ja.h == jb.h && ja.x == jb.x && ja.y == jb.y &&
                 ja.rec == jb.rec && ja.hs == jb.hs && ja.vs == jb.vs && ja.dmvr == jb.dmvr && ja.hf_idx == jb.hf_idx &&
                 ja.vf_idx == jb.vf_idx && ja.pic_w == jb.pic_w && ja.pic_h == jb.pic_h;
 #pragma unroll

@@ -416,6 +416,8 @@ void vvc355_pred_fused_batch(void *stream, int bd, const vvc355_pred_job *jobs_d
  *   x, y, w, h   position and size in this component's samples; pic_w, pic_h likewise
  *   hf_idx/vf_idx  filter set (vvc_inter.c:382-383: 0 regular, 1 half-sample alternative)
  *   weight_flag, denom, w0, w1, o0, o1   what derive_weight (:137-167) returns for this component
+ *   pred_flag    uni-predicted blocks (luma_mc_uni :222-251 / chroma_mc_uni :298-328: put_uni / put_uni_w, no DMVR / BDOF) go through
+ *                the same entry with pred_flag 1 or 2; their weights are derive_weight_uni's (denom, w0 = wx, o0 = ox)
  * Launch the luma jobs of a frame first, then the chroma jobs that point at their records.
  */
 typedef struct vvc355_bipred_job {
@@ -425,7 +427,8 @@ typedef struct vvc355_bipred_job {
     int16_t  x, y, w, h, pic_w, pic_h;
     int16_t  denom, w0, w1, o0, o1;
     uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
-    uint8_t  pad_[6];
+    uint8_t  pred_flag;          /* 0 or 3: bi-prediction; 1: list 0 only; 2: list 1 only (mvf->pred_flag) */
+    uint8_t  pad_[5];
 } vvc355_bipred_job;
 
 typedef struct vvc355_bipred_result {

@@ -409,7 +409,7 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
     const ptrdiff_t rstride[2] = { job->ref0_stride, job->ref1_stride };
     orc_bipred_result *rec = (orc_bipred_result *)(uintptr_t)job->rec;
     int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
-    int bdof = !chroma && job->bdof;
+    int bdof = !chroma && job->bdof && !(job->pred_flag == 1 || job->pred_flag == 2);
     static _Thread_local int16_t tmpbuf[2][(ORC_PB + 4) * ORC_PB];
     static _Thread_local uint8_t emu[2 * EMU_STRIDE * (ORC_PB + 8)];
 
@@ -417,7 +417,7 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
         /* chroma follows the luma block's refined motion (vvc_inter.c:622-628: mv is the one derive_sb_mv refined) */
         for (int k = 0; k < 4; k++) mv[k] = rec->mv[k];
     }
-    if (!chroma && job->dmvr) {
+    if (!chroma && job->dmvr && !(job->pred_flag == 1 || job->pred_flag == 2)) {
         /* dmvr_mv_refine, vvc_inter.c:685-748 */
         int sad[5][5], min_dx = 2, min_dy = 2, min_sad, searched = 0;
         for (int i = 0; i < 2; i++) {
@@ -466,11 +466,14 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
         rec->bdof = bdof;
     }
 
-    /* luma_mc_bi :253-296 / chroma_mc_bi :330-369 */
+    /* luma_mc_bi :253-296 / chroma_mc_bi :330-369; uni-prediction: luma_mc_uni :222-251 / chroma_mc_uni :298-328 */
+    const int uni = job->pred_flag == 1 || job->pred_flag == 2;
     const int before = chroma ? 1 : 3, after = chroma ? 2 : 4, extra = before + after;
     const int shx = 4 + (chroma ? job->hs : 0), shy = 4 + (chroma ? job->vs : 0);
     int16_t *tmp[2] = { tmpbuf[0] + 2 * ORC_PB + 32, tmpbuf[1] + 2 * ORC_PB + 32 };      /* room for the BDOF ring */
     for (int i = 0; i < 2; i++) {
+        if (uni && i != job->pred_flag - 1)
+            continue;
         const int mvx = mv[2 * i], mvy = mv[2 * i + 1];
         const int mx = chroma ? (mvx & ((1 << shx) - 1)) << (1 - job->hs) : mvx & 15;
         const int my = chroma ? (mvy & ((1 << shy) - 1)) << (1 - job->vs) : mvy & 15;
@@ -478,7 +481,7 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
         const int8_t *hf = chroma ? orc_tab_inter_chroma_filters + (job->hf_idx * 32 + mx) * 4 : orc_tab_inter_luma_filters + (job->hf_idx * 16 + mx) * 8;
         const int8_t *vf = chroma ? orc_tab_inter_chroma_filters + (job->vf_idx * 32 + my) * 4 : orc_tab_inter_luma_filters + (job->vf_idx * 16 + my) * 8;
         int cx0 = 0, cy0 = 0, cx1 = job->pic_w - 1, cy1 = job->pic_h - 1;
-        if (job->dmvr) {
+        if (job->dmvr && !uni) {
             /* emulated_edge_dmvr :61-88: the readable rectangle is the window of the UNREFINED block */
             const int x_sb = job->x + (job->mv[2 * i] >> shx), y_sb = job->y + (job->mv[2 * i + 1] >> shy);
             cx0 = orc_min(orc_max(x_sb - before, 0), job->pic_w - 1);
@@ -489,6 +492,14 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
         uint8_t *buf = emu + (size_t)i * EMU_STRIDE * (ORC_PB + 8);
         emu_window(wide, buf, ref[i], rstride[i], ox - before, oy - before, w + extra, h + extra, cx0, cy0, cx1, cy1);
         const uint8_t *src = buf + (((ptrdiff_t)before * EMU_STRIDE + before) << wide);
+        if (uni) {
+            uint8_t *udst = (uint8_t *)(uintptr_t)job->dst;
+            if (job->weight_flag)
+                orc_put_uni_w(bd, chroma, !!my, !!mx, udst, job->dst_stride, src, (ptrdiff_t)EMU_STRIDE << wide, h, job->denom, job->w0, job->o0, hf, vf, w);
+            else
+                orc_put_uni(bd, chroma, !!my, !!mx, udst, job->dst_stride, src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
+            return;
+        }
         orc_put(bd, chroma, !!my, !!mx, tmp[i], src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
         if (bdof)
             orc_bdof_fetch_samples(bd, tmp[i], src, (ptrdiff_t)EMU_STRIDE << wide, mx, my, w, h);

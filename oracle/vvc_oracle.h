@@ -108,7 +108,8 @@ typedef struct orc_bipred_job {
     int16_t  x, y, w, h, pic_w, pic_h;
     int16_t  denom, w0, w1, o0, o1;
     uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
-    uint8_t  pad_[6];
+    uint8_t  pred_flag;          /* 0 or 3: bi-prediction; 1: list 0 only; 2: list 1 only (mvf->pred_flag) */
+    uint8_t  pad_[5];
 } orc_bipred_job;
 typedef struct orc_bipred_result {
     int32_t mv[4];

@@ -56,6 +56,10 @@ def test_bipred_frame(dev, orc, bd):
             dmvr = bdof = 1
         if w < 8 or h < 8 or h == 12:
             dmvr = bdof = 0                    # the tools need at least 8x8 and multiples of 4 / the DMVR sub-block sizes
+        pred_flag = int(rng.choice([1, 2])) if (kind == 2 and rng.random() < 0.5) else 3      # some uni-predicted blocks
+        if pred_flag != 3:
+            dmvr = bdof = 0
+            wf = int(rng.random() < 0.4)
         wf = int(rng.random() < 0.3 and not dmvr)
         for c in range(3):
             j = abi.BipredJob()
@@ -65,7 +69,7 @@ def test_bipred_frame(dev, orc, bd):
             for k, v in enumerate(mv0 + mv1):
                 j.mv[k] = v
             j.chroma, j.hs, j.vs = int(c > 0), 1, 1
-            j.dmvr, j.bdof, j.weight_flag = dmvr, bdof, wf
+            j.dmvr, j.bdof, j.weight_flag, j.pred_flag = dmvr, bdof, wf, pred_flag
             j.hf_idx = j.vf_idx = int(rng.integers(0, 2)) if c == 0 else 0
             if c:
                 j.hf_idx, j.vf_idx = host_jobs[-c][0].hf_idx, host_jobs[-c][0].vf_idx
