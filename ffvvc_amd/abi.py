@@ -113,6 +113,7 @@ BATCH_SIGNATURES = {
     "bipred_chroma_batch": ("v", "pipi"),
     "affine_batch":     ("v", "pipi"),
     "deblock_frame_pass": ("v", "pipp"),
+    "sao_frame_pass":   ("v", "pipp"),
 }
 
 
@@ -233,6 +234,24 @@ class BipredResult(ctypes.Structure):
     """Mirror of vvc355_bipred_result."""
     _fields_ = [("mv", ctypes.c_int32 * 4), ("bdof", ctypes.c_int32), ("min_sad", ctypes.c_int32),
                 ("searched", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class SaoCtb(ctypes.Structure):
+    """Mirror of vvc355_sao_ctb."""
+    _fields_ = [("offset_val", (ctypes.c_int16 * 5) * 3), ("type_idx", ctypes.c_uint8 * 3), ("band_position", ctypes.c_uint8 * 3),
+                ("eo_class", ctypes.c_uint8 * 3), ("pad_", ctypes.c_uint8)]
+
+
+class SaoFrame(ctypes.Structure):
+    """Mirror of vvc355_sao_frame (and of the oracle's orc_sao_frame)."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64 * 3), ("src", ctypes.c_uint64 * 3), ("sao", ctypes.c_uint64), ("slice_idx", ctypes.c_uint64),
+        ("ctb_to_col_bd", ctypes.c_uint64), ("ctb_to_row_bd", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32 * 3), ("src_stride", ctypes.c_int32 * 3),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32), ("ctb_height", ctypes.c_int32),
+        ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("n_comp", ctypes.c_uint8),
+        ("lfase", ctypes.c_uint8), ("no_tile_filter", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+    ]
 
 
 class DeblockFrame(ctypes.Structure):

@@ -219,10 +219,9 @@ __device__ __forceinline__ void sao_edge8(const uint32_t (&c)[4], const uint32_t
 // samples.  A workgroup covers 128 columns x 64 rows (narrower rectangles: fewer lanes across, more rows).  Only rows / lanes that
 // touch the rectangle's outer ring where a border / restore flag is set take the per-sample path of sao_restore_px.
 template <int BD>
-__global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
+__device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job)
 {
     using px_t = typename Px<BD>::type;
-    const vvc355_sao_job job = load_uniform(jobs + blockIdx.y);
     const int w = job.w, h = job.h, type = job.type;
     const int lxl = w > 64 ? 4 : w > 32 ? 3 : w > 16 ? 2 : w > 8 ? 1 : 0;        // log2 of the lanes across
     const int x0 = (threadIdx.x & ((1 << lxl) - 1)) * 8;
@@ -338,6 +337,77 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
             for (int j = 0; j < w - x0; j++) drow[x0 + j] = (px_t)((out[r][j >> 1] >> ((j & 1) * 16)) & 0xffff);
         }
     }
+}
+
+template <int BD>
+__global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
+{
+    const vvc355_sao_job job = load_uniform(jobs + blockIdx.y);
+    sao_vec_body<BD>(job);
+}
+
+// SAO stage driver (ff_vvc_sao_filter, vvc_filter.c:154-300): blockIdx.y = CTB * n_comp + component.  The job the vector body
+// works on is derived here, on the scalar unit, from the per-CTB tables: picture-border flags (:172-175), unfilterable slice /
+// tile edges (:177-215), type / band position / edge class / offsets of the component.  CTBs without SAO are copied.
+template <int BD>
+__global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *__restrict__ fp)
+{
+    using px_t = typename Px<BD>::type;
+    const vvc355_sao_frame F = load_uniform(fp);
+    const int ctb = blockIdx.y / F.n_comp, c = blockIdx.y - ctb * F.n_comp;
+    const int yc = ctb / F.ctb_width, xc = ctb - yc * F.ctb_width;
+    const vvc355_sao_ctb P = load_uniform((const vvc355_sao_ctb *)F.sao + ctb);
+    const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
+    const int pw = F.width >> hs, ph = F.height >> vs;
+    const int x0 = (xc << F.ctb_log2) >> hs, y0 = (yc << F.ctb_log2) >> vs;
+    vvc355_sao_job job = {};
+    job.w = (int16_t)min((1 << F.ctb_log2) >> hs, pw - x0);
+    job.h = (int16_t)min((1 << F.ctb_log2) >> vs, ph - y0);
+    job.dst = F.dst[c] + (uint64_t)((ptrdiff_t)y0 * F.dst_stride[c] + x0 * (int)sizeof(px_t));
+    job.src = F.src[c] + (uint64_t)((ptrdiff_t)y0 * F.src_stride[c] + x0 * (int)sizeof(px_t));
+    job.dst_stride = F.dst_stride[c]; job.src_stride = F.src_stride[c];
+    const int type_idx = P.type_idx[c];
+    if (type_idx == 0) {
+        // SAO not applied: the samples pass through (16-byte vectors where the row allows, else sample by sample)
+        const int w = job.w, h = job.h, wv = w >> 3;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (wv + 1) * h; i += gridDim.x * 256) {
+            const int y = i / (wv + 1), xv = i - y * (wv + 1);
+            const px_t *sp = (const px_t *)((const uint8_t *)job.src + row_off(y, job.src_stride)) + xv * 8;
+            px_t *dp = (px_t *)((uint8_t *)job.dst + row_off(y, job.dst_stride)) + xv * 8;
+            if (xv < wv) {
+                uint32_t v[4];
+                load8_pk<BD>(sp, v);
+                store8_pk<BD>(dp, v);
+            } else {
+                for (int x = 0; x < (w & 7); x++) dp[x] = sp[x];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) job.offset_val[k] = P.offset_val[c][k];
+    job.type = type_idx == 1 ? 1 : 3;
+    job.eo = P.eo_class[c]; job.band_position = P.band_position[c];
+    const int eL = xc == 0, eT = yc == 0, eR = xc == F.ctb_width - 1, eB = yc == F.ctb_height - 1;
+    job.borders[0] = eL; job.borders[1] = eT; job.borders[2] = eR; job.borders[3] = eB;
+    const int restore = F.no_tile_filter || !F.lfase;
+    job.restore = restore;
+    if (restore) {
+        const int16_t *slice = (const int16_t *)F.slice_idx;
+        const int16_t *col_bd = (const int16_t *)F.ctb_to_col_bd, *row_bd = (const int16_t *)F.ctb_to_row_bd;
+        const int cw = F.ctb_width, nl = !F.lfase;
+        const int me = slice[ctb];
+        int lt = 0, rt = 0, ut = 0, bt = 0;
+        if (!eL) { lt = F.no_tile_filter && col_bd[xc] == xc; job.vert_edge[0] = (nl && me != slice[ctb - 1]) || lt; }
+        if (!eR) { rt = F.no_tile_filter && col_bd[xc] != col_bd[xc + 1]; job.vert_edge[1] = (nl && me != slice[ctb + 1]) || rt; }
+        if (!eT) { ut = F.no_tile_filter && row_bd[yc] == yc; job.horiz_edge[0] = (nl && me != slice[ctb - cw]) || ut; }
+        if (!eB) { bt = F.no_tile_filter && row_bd[yc] != row_bd[yc + 1]; job.horiz_edge[1] = (nl && me != slice[ctb + cw]) || bt; }
+        if (!eL && !eT) job.diag_edge[0] = (nl && me != slice[ctb - cw - 1]) || lt || ut;
+        if (!eT && !eR) job.diag_edge[1] = (nl && me != slice[ctb - cw + 1]) || rt || ut;
+        if (!eR && !eB) job.diag_edge[2] = (nl && me != slice[ctb + cw + 1]) || rt || bt;
+        if (!eL && !eB) job.diag_edge[3] = (nl && me != slice[ctb + cw - 1]) || lt || bt;
+    }
+    sao_vec_body<BD>(job);
 }
 
 // ------------------------------------------------------------------------------------------------ deblock
@@ -836,6 +906,16 @@ extern "C" {
 void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
     launch_sao(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
+}
+
+void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_dev, const vvc355_sao_frame *frame_host)
+{
+    const vvc355_sao_frame &F = *frame_host;       // host copy: geometry only
+    const int n = F.ctb_width * F.ctb_height * F.n_comp;
+    if (n <= 0) return;
+    const int ctb = 1 << F.ctb_log2;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_frame_kernel<BD>), dim3((ctb + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, frame_dev));
+    HIP_CHECK(hipGetLastError());
 }
 
 void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_h)

@@ -502,6 +502,37 @@ typedef struct vvc355_deblock_frame {
 /* frame_dev: DEVICE address of one descriptor; the launch covers every edge unit of the pass */
 void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame *frame_dev, const vvc355_deblock_frame *frame_host);
 
+/* ------------------------------------------------------------------ SAO stage driver (loopfilter.hip) */
+
+/*
+ * SAO of a whole picture straight from the decoder's per-CTB tables: what ff_vvc_sao_filter (vvc_filter.c:154-300) does per
+ * CTB — picture-border flags, the "unfilterable edge" flags from slice indices and tile boundaries (:177-215), the
+ * per-component type / band position / edge class / offsets — then band_filter, or edge_filter + edge_restore.  No job
+ * array; CTBs with SAO switched off are copied.  Reads the deblocked picture (src), writes another (dst), so the
+ * reference's saved border lines (sao_pixel_buffer_h / _v, :100-152) are not needed.
+ */
+typedef struct vvc355_sao_ctb {
+    int16_t  offset_val[3][5];    /* SAOParams.offset_val */
+    uint8_t  type_idx[3];         /* 0 not applied, 1 band, 2 edge (SAO_NOT_APPLIED / SAO_BAND / SAO_EDGE) */
+    uint8_t  band_position[3], eo_class[3];
+    uint8_t  pad_;
+} vvc355_sao_ctb;
+
+typedef struct vvc355_sao_frame {
+    uint64_t dst[3], src[3];      /* post- and pre-SAO planes (the reference filters in place from saved border lines) */
+    uint64_t sao;                 /* vvc355_sao_ctb per CTB, raster order (fc->tab.sao) */
+    uint64_t slice_idx;           /* int16 per CTB (fc->tab.slice_idx) */
+    uint64_t ctb_to_col_bd, ctb_to_row_bd;   /* int16 per CTB column (ctb_width + 1 entries) / row (pps->ctb_to_col_bd, _row_bd) */
+    int32_t  dst_stride[3], src_stride[3];   /* bytes */
+    int32_t  width, height, ctb_width, ctb_height;
+    uint8_t  ctb_log2, hs, vs, n_comp;
+    uint8_t  lfase;               /* pps_loop_filter_across_slices_enabled_flag */
+    uint8_t  no_tile_filter;      /* num_tiles_in_pic > 1 && !pps_loop_filter_across_tiles_enabled_flag */
+    uint8_t  pad_[2];
+} vvc355_sao_frame;
+
+void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_dev, const vvc355_sao_frame *frame_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -769,3 +769,69 @@ ORC_API void orc_deblock_frame_pass(int bd, const orc_deblock_frame *f)
     }
 #undef TU
 }
+
+
+/* ------------------------------------------------------------------ callers: SAO of a picture
+ *
+ * ff_vvc_sao_filter (vvc_filter.c:154-300) per CTB, flattened: edges[] = picture borders (:172-175), vert / horiz / diag_edge from
+ * slice indices and tile boundaries when filtering across them is off (:177-215), then per component band_filter, or the
+ * padded copy (:243-287, here taken from the pre-SAO plane instead of the saved border lines) + edge_filter + edge_restore.
+ */
+#define SAO_EDGE_STRIDE (2 * ORC_PB + 64)          /* 2*MAX_PB_SIZE + AV_INPUT_BUFFER_PADDING_SIZE, bytes (vvcdsp.h:140) */
+ORC_API void orc_sao_frame_pass(int bd, const orc_sao_frame *f)
+{
+    const int wide = bd > 8;
+    const orc_sao_ctb *tab = (const orc_sao_ctb *)(uintptr_t)f->sao;
+    const int16_t *slice = (const int16_t *)(uintptr_t)f->slice_idx;
+    const int16_t *col_bd = (const int16_t *)(uintptr_t)f->ctb_to_col_bd, *row_bd = (const int16_t *)(uintptr_t)f->ctb_to_row_bd;
+    const int restore = f->no_tile_filter || !f->lfase;
+    static _Thread_local uint8_t buf[(ORC_PB + 2) * SAO_EDGE_STRIDE];
+#define SL(x, y) slice[(y) * f->ctb_width + (x)]
+    for (int yc = 0; yc < f->ctb_height; yc++)
+        for (int xc = 0; xc < f->ctb_width; xc++) {
+            const orc_sao_ctb *sao = tab + yc * f->ctb_width + xc;
+            int edges[4] = { xc == 0, yc == 0, xc == f->ctb_width - 1, yc == f->ctb_height - 1 };
+            uint8_t vert_edge[2] = { 0, 0 }, horiz_edge[2] = { 0, 0 }, diag_edge[4] = { 0, 0, 0, 0 };
+            int lt = 0, rt = 0, ut = 0, bt = 0;
+            if (restore) {
+                const int me = SL(xc, yc);
+                if (!edges[0]) { lt = f->no_tile_filter && col_bd[xc] == xc; vert_edge[0] = (!f->lfase && me != SL(xc - 1, yc)) || lt; }
+                if (!edges[2]) { rt = f->no_tile_filter && col_bd[xc] != col_bd[xc + 1]; vert_edge[1] = (!f->lfase && me != SL(xc + 1, yc)) || rt; }
+                if (!edges[1]) { ut = f->no_tile_filter && row_bd[yc] == yc; horiz_edge[0] = (!f->lfase && me != SL(xc, yc - 1)) || ut; }
+                if (!edges[3]) { bt = f->no_tile_filter && row_bd[yc] != row_bd[yc + 1]; horiz_edge[1] = (!f->lfase && me != SL(xc, yc + 1)) || bt; }
+                if (!edges[0] && !edges[1]) diag_edge[0] = (!f->lfase && me != SL(xc - 1, yc - 1)) || lt || ut;
+                if (!edges[1] && !edges[2]) diag_edge[1] = (!f->lfase && me != SL(xc + 1, yc - 1)) || rt || ut;
+                if (!edges[2] && !edges[3]) diag_edge[2] = (!f->lfase && me != SL(xc + 1, yc + 1)) || rt || bt;
+                if (!edges[0] && !edges[3]) diag_edge[3] = (!f->lfase && me != SL(xc - 1, yc + 1)) || lt || bt;
+            }
+            for (int c = 0; c < f->n_comp; c++) {
+                const int hs = c ? f->hs : 0, vs = c ? f->vs : 0;
+                const int pw = f->width >> hs, ph = f->height >> vs;
+                const int x0 = (xc << f->ctb_log2) >> hs, y0 = (yc << f->ctb_log2) >> vs;
+                const int w = orc_min((1 << f->ctb_log2) >> hs, pw - x0), h = orc_min((1 << f->ctb_log2) >> vs, ph - y0);
+                const uint8_t *splane = (const uint8_t *)(uintptr_t)f->src[c];
+                uint8_t *dst = (uint8_t *)(uintptr_t)f->dst[c] + (ptrdiff_t)y0 * f->dst_stride[c] + ((ptrdiff_t)x0 << wide);
+                const uint8_t *src = splane + (ptrdiff_t)y0 * f->src_stride[c] + ((ptrdiff_t)x0 << wide);
+                if (sao->type_idx[c] == 1) {
+                    orc_sao_band_filter(bd, dst, src, f->dst_stride[c], f->src_stride[c], sao->offset_val[c], sao->band_position[c], w, h);
+                } else if (sao->type_idx[c] == 2) {
+                    /* the CTB with the one-sample apron that exists inside the picture (:243-287) */
+                    uint8_t *b0 = buf + SAO_EDGE_STRIDE + 64;
+                    for (int y = -1; y <= h; y++)
+                        for (int x = -1; x <= w; x++) {
+                            const int sx = x0 + x, sy = y0 + y;
+                            if (sx < 0 || sy < 0 || sx >= pw || sy >= ph)
+                                continue;
+                            orc_st(b0 + (ptrdiff_t)y * SAO_EDGE_STRIDE, x, orc_ld(splane + (ptrdiff_t)sy * f->src_stride[c], sx, wide), wide);
+                        }
+                    orc_sao_edge_filter(bd, dst, b0, f->dst_stride[c], sao->offset_val[c], sao->eo_class[c], w, h);
+                    orc_sao_edge_restore(bd, restore, dst, b0, f->dst_stride[c], SAO_EDGE_STRIDE, sao->offset_val[c], sao->eo_class[c], edges,
+                                         w, h, vert_edge, horiz_edge, diag_edge);
+                } else {
+                    for (int y = 0; y < h; y++)
+                        memcpy(dst + (ptrdiff_t)y * f->dst_stride[c], src + (ptrdiff_t)y * f->src_stride[c], (size_t)w << wide);
+                }
+            }
+        }
+#undef SL
+}

@@ -151,6 +151,28 @@ typedef struct orc_deblock_frame {
 } orc_deblock_frame;
 void orc_deblock_frame_pass(int bd, const orc_deblock_frame *f);
 
+/* ---- SAO of a picture from the decoder's per-CTB tables (orc_filter.c, "ff_vvc_sao_filter"); layouts as in include/vvc_mi355.h ---- */
+typedef struct orc_sao_ctb {
+    int16_t  offset_val[3][5];    /* SAOParams.offset_val */
+    uint8_t  type_idx[3];         /* 0 not applied, 1 band, 2 edge (SAO_NOT_APPLIED / SAO_BAND / SAO_EDGE) */
+    uint8_t  band_position[3], eo_class[3];
+    uint8_t  pad_;
+} orc_sao_ctb;
+
+typedef struct orc_sao_frame {
+    uint64_t dst[3], src[3];      /* post- and pre-SAO planes (the reference filters in place from saved border lines) */
+    uint64_t sao;                 /* orc_sao_ctb per CTB, raster order (fc->tab.sao) */
+    uint64_t slice_idx;           /* int16 per CTB (fc->tab.slice_idx) */
+    uint64_t ctb_to_col_bd, ctb_to_row_bd;   /* int16 per CTB column (ctb_width + 1 entries) / row (pps->ctb_to_col_bd, _row_bd) */
+    int32_t  dst_stride[3], src_stride[3];   /* bytes */
+    int32_t  width, height, ctb_width, ctb_height;
+    uint8_t  ctb_log2, hs, vs, n_comp;
+    uint8_t  lfase;               /* pps_loop_filter_across_slices_enabled_flag */
+    uint8_t  no_tile_filter;      /* num_tiles_in_pic > 1 && !pps_loop_filter_across_tiles_enabled_flag */
+    uint8_t  pad_[2];
+} orc_sao_frame;
+void orc_sao_frame_pass(int bd, const orc_sao_frame *f);
+
 typedef struct orc_intra_job {
     uint64_t plane;
     int32_t  stride;

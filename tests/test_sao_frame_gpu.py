@@ -72,3 +72,63 @@ def test_sao_ctb_batch(dev, orc, bd, dims):
     got = d_dst.to_host(pitched.dtype, pitched.shape)[:, :width]
     bad = np.argwhere(got != want)
     assert len(bad) == 0, f"{len(bad)} samples differ, first at {bad[0].tolist()}"
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("mode", ["across", "slices", "tiles", "both"])
+def test_sao_frame_pass(dev, orc, bd, mode):
+    """The SAO stage driver (vvc355_sao_frame_pass: per-CTB flags and parameters derived on the device from the decoder's
+    tables) vs the oracle's restatement of ff_vvc_sao_filter on the same tables; 4:2:0, partial CTBs at the right / bottom."""
+    import ctypes
+    orc.orc_sao_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.SaoFrame)]
+    orc.orc_sao_frame_pass.restype = None
+    rng = np.random.default_rng(0x5EED0850 + bd + len(mode))
+    w, h, ctb_log2 = 328, 200, 6
+    ctb = 1 << ctb_log2
+    cw, ch = (w + ctb - 1) // ctb, (h + ctb - 1) // ctb
+    dims = [(w, h), (w // 2, h // 2), (w // 2, h // 2)]
+    isz = 1 if bd == 8 else 2
+    src = [rand_pixels(rng, (d[1], d[0]), bd) for d in dims]
+    if bd > 8:
+        src = [(p >> 2 << 2).astype(p.dtype) for p in src]
+    want = [np.full_like(p, 0x21) for p in src]
+    p_src = [batch.to_pitched(p) for p in src]
+    d_src = [batch.DeviceBuffer.from_host(p) for p in p_src]
+    d_dst = [batch.DeviceBuffer.from_host(np.full_like(p, 0x21)) for p in p_src]
+    tab = (abi.SaoCtb * (cw * ch))()
+    for t in tab:
+        for c in range(3):
+            t.type_idx[c], t.band_position[c], t.eo_class[c] = int(rng.integers(0, 3)), int(rng.integers(0, 32)), int(rng.integers(0, 4))
+            for k in range(1, 5):
+                t.offset_val[c][k] = int(rng.integers(-(1 << (bd - 5)) + 1, 1 << (bd - 5)))
+    # slices: horizontal bands of CTB rows cut at a random CTB; tiles: two columns x two rows
+    cut = int(rng.integers(1, cw * ch))
+    slice_idx = (np.arange(cw * ch) >= cut).astype(np.int16) + (np.arange(cw * ch) >= min(cw * ch - 1, cut + cw + 1)).astype(np.int16)
+    col_bd = np.array([0 if x < 3 else 3 for x in range(cw)] + [cw], np.int16)
+    row_bd = np.array([0 if y < 2 else 2 for y in range(ch)] + [ch], np.int16)
+    tabs_host = [np.frombuffer(bytes(tab), np.uint8).copy(), slice_idx, col_bd, row_bd]
+    tabs_dev = [batch.DeviceBuffer.from_host(t) for t in tabs_host]
+
+    def fill(f, dst_ptrs, src_ptrs, dstrides, sstrides, tp):
+        for c in range(3):
+            f.dst[c], f.src[c], f.dst_stride[c], f.src_stride[c] = dst_ptrs[c], src_ptrs[c], dstrides[c], sstrides[c]
+        f.sao, f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = tp
+        f.width, f.height, f.ctb_width, f.ctb_height = w, h, cw, ch
+        f.ctb_log2, f.hs, f.vs, f.n_comp = ctb_log2, 1, 1, 3
+        f.lfase = int(mode in ("across", "tiles"))
+        f.no_tile_filter = int(mode in ("tiles", "both"))
+
+    hf = abi.SaoFrame()
+    fill(hf, [P(p) for p in want], [P(p) for p in src], [d[0] * isz for d in dims], [d[0] * isz for d in dims], [P(t) for t in tabs_host])
+    orc.orc_sao_frame_pass(bd, ctypes.byref(hf))
+    df = abi.SaoFrame()
+    fill(df, [d.ptr for d in d_dst], [d.ptr for d in d_src], [p.shape[1] * isz for p in p_src], [p.shape[1] * isz for p in p_src],
+         [d.ptr for d in tabs_dev])
+    d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
+    dev.vvc355_sao_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df))
+    dev.vvc355_stream_sync(None)
+    for c in range(3):
+        got = d_dst[c].to_host(p_src[c].dtype, p_src[c].shape)
+        bad = np.argwhere(got[:, :dims[c][0]] != want[c])
+        assert len(bad) == 0, f"mode={mode} component {c}: {len(bad)} samples differ, first at {bad[0].tolist()}"
+        assert np.all(got[:, dims[c][0]:] == 0x21)
