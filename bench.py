@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+SAO_TABLES = False             # --sao-tables: SAO through the stage driver (parameters derived on the device from per-CTB tables)
 DEBLOCK_JOBS = True            # --deblock-tables switches to the stage driver that derives every edge's parameters from side tables
 AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
@@ -398,7 +399,28 @@ def build_chain(lib, torch, fr):
     sao_all = np.concatenate(sj)
     d_sao = fr.upload(sao_all.view(np.uint8))
     n_sao = len(sao_all)
-    chain.append(Stage("sao", f"sao_vec_kernel<{bd}>", lambda st: lib.vvc355_sao_ctb_batch(st, bd, ptr(d_sao), n_sao, CTB), frame_bytes * 2))
+    if not SAO_TABLES:
+        chain.append(Stage("sao", f"sao_vec_kernel<{bd}>", lambda st: lib.vvc355_sao_ctb_batch(st, bd, ptr(d_sao), n_sao, CTB), frame_bytes * 2))
+    else:
+        # the stage driver: the same per-CTB parameters as a table (fc->tab.sao), one slice, no tiles
+        tab = batch.job_array(abi.SaoCtb, fr.n_ctus)
+        for c in range(3):
+            tab["offset_val"][:, c, :] = sj[c]["offset_val"]
+            tab["type_idx"][:, c] = np.where(sj[c]["type"] == 3, 2, 1)
+            tab["band_position"][:, c], tab["eo_class"][:, c] = sj[c]["band_position"], sj[c]["eo"]
+        d_tab = fr.upload(tab.view(np.uint8))
+        d_slice = fr.upload(np.zeros(fr.n_ctus, np.int16))
+        d_col, d_row = fr.upload(np.zeros(fr.ncx + 1, np.int16)), fr.upload(np.zeros(fr.ncy + 1, np.int16))
+        sf = abi.SaoFrame()
+        for c in range(3):
+            sf.dst[c], sf.src[c], sf.dst_stride[c], sf.src_stride[c] = ptr(sao[c]), ptr(rec[c]), fr.pitch(sao[c]), fr.pitch(rec[c])
+        sf.sao, sf.slice_idx, sf.ctb_to_col_bd, sf.ctb_to_row_bd = ptr(d_tab), ptr(d_slice), ptr(d_col), ptr(d_row)
+        sf.width, sf.height, sf.ctb_width, sf.ctb_height = fr.width, fr.height, fr.ncx, fr.ncy
+        sf.ctb_log2, sf.hs, sf.vs, sf.n_comp, sf.lfase, sf.no_tile_filter = 7, 1, 1, 3, 1, 0
+        d_sf = fr.upload(np.frombuffer(bytes(sf), np.uint8))
+        fr.keep.append(sf)
+        chain.append(Stage("sao", f"sao_frame_kernel<{bd}>", lambda st: lib.vvc355_sao_frame_pass(st, bd, ptr(d_sf), ctypes.addressof(sf)),
+                           frame_bytes * 2))
 
     # ---------------------------------------------------------------- ALF luma: classify + coefficient gather + 7x7 diamond, fused
     sets = alf_filter_sets(rng, 8)
@@ -580,6 +602,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
+    ap.add_argument("--sao-tables", action="store_true", help="SAO through vvc355_sao_frame_pass (per-CTB tables) instead of host-built jobs")
     ap.add_argument("--deblock-tables", action="store_true",
                     help="profiling aid: deblock through vvc355_deblock_frame_pass (parameters derived on the device from side tables)")
     ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
@@ -589,7 +612,8 @@ def parse_args():
 
 def main():
     args = parse_args()
-    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS
+    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES
+    SAO_TABLES = args.sao_tables
     DEBLOCK_JOBS = not args.deblock_tables
     MC_TOOLS = args.mc_tools & 3
     AFFINE_FRAC = args.affine_frac

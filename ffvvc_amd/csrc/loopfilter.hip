@@ -346,6 +346,10 @@ __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__re
     sao_vec_body<BD>(job);
 }
 
+// a[c] for c in 0..2 as selects between the three values: indexing a register copy of a descriptor with a run-time index would
+// put the whole descriptor into scratch memory
+template <typename T> __device__ __forceinline__ T sel3(int c, const T (&a)[3]) { return c == 0 ? a[0] : c == 1 ? a[1] : a[2]; }
+
 // SAO stage driver (ff_vvc_sao_filter, vvc_filter.c:154-300): blockIdx.y = CTB * n_comp + component.  The job the vector body
 // works on is derived here, on the scalar unit, from the per-CTB tables: picture-border flags (:172-175), unfilterable slice /
 // tile edges (:177-215), type / band position / edge class / offsets of the component.  CTBs without SAO are copied.
@@ -363,10 +367,10 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
     vvc355_sao_job job = {};
     job.w = (int16_t)min((1 << F.ctb_log2) >> hs, pw - x0);
     job.h = (int16_t)min((1 << F.ctb_log2) >> vs, ph - y0);
-    job.dst = F.dst[c] + (uint64_t)((ptrdiff_t)y0 * F.dst_stride[c] + x0 * (int)sizeof(px_t));
-    job.src = F.src[c] + (uint64_t)((ptrdiff_t)y0 * F.src_stride[c] + x0 * (int)sizeof(px_t));
-    job.dst_stride = F.dst_stride[c]; job.src_stride = F.src_stride[c];
-    const int type_idx = P.type_idx[c];
+    job.dst_stride = sel3(c, F.dst_stride); job.src_stride = sel3(c, F.src_stride);
+    job.dst = sel3(c, F.dst) + (uint64_t)((ptrdiff_t)y0 * job.dst_stride + x0 * (int)sizeof(px_t));
+    job.src = sel3(c, F.src) + (uint64_t)((ptrdiff_t)y0 * job.src_stride + x0 * (int)sizeof(px_t));
+    const int type_idx = sel3(c, P.type_idx);
     if (type_idx == 0) {
         // SAO not applied: the samples pass through (16-byte vectors where the row allows, else sample by sample)
         const int w = job.w, h = job.h, wv = w >> 3;
@@ -385,9 +389,9 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
         return;
     }
 #pragma unroll
-    for (int k = 0; k < 5; k++) job.offset_val[k] = P.offset_val[c][k];
+    for (int k = 0; k < 5; k++) job.offset_val[k] = c == 0 ? P.offset_val[0][k] : c == 1 ? P.offset_val[1][k] : P.offset_val[2][k];
     job.type = type_idx == 1 ? 1 : 3;
-    job.eo = P.eo_class[c]; job.band_position = P.band_position[c];
+    job.eo = sel3(c, P.eo_class); job.band_position = sel3(c, P.band_position);
     const int eL = xc == 0, eT = yc == 0, eR = xc == F.ctb_width - 1, eB = yc == F.ctb_height - 1;
     job.borders[0] = eL; job.borders[1] = eT; job.borders[2] = eR; job.borders[3] = eB;
     const int restore = F.no_tile_filter || !F.lfase;
@@ -790,10 +794,48 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
     const int ctb = (ux >> F.ctb_log2) + (uy >> F.ctb_log2) * F.ctb_width;
     const int8_t *dbp = (const int8_t *)F.db_params + ctb * 6;
     const int shift = vertical ? vs : hs, lines = c ? (shift ? 2 : 4) : 4, nseg = 8 / lines;
-    const uint8_t *bs_tab = (const uint8_t *)F.bs[c];
-    uint8_t *plane = (uint8_t *)F.plane[c];
-    const int stride = F.stride[c], pxstride = stride / (int)sizeof(px_t);
+    const uint8_t *bs_tab = (const uint8_t *)sel3(c, F.bs);
+    uint8_t *plane = (uint8_t *)sel3(c, F.plane);
+    const int stride = sel3(c, F.stride), pxstride = stride / (int)sizeof(px_t);
     const int xs = vertical ? 1 : pxstride, ys = vertical ? pxstride : 1;
+    if (!c) {
+        // luma: this lane's one 4-line segment
+        const int seg = t & 1;
+        const int x = vertical ? e : u + 4 * seg, y = vertical ? u + 4 * seg : e;
+        if (vertical ? y >= F.height : x >= F.width)
+            return;
+        const int tu = (y >> 2) * F.min_tu_width + (x >> 2);
+        const int bs = gld<uint8_t>(bs_tab + tu);
+        if (!bs)
+            return;
+        const int xp = x - vertical, yp = y - !vertical;
+        uint8_t *pix = plane + row_off(y, stride) + x * (int)sizeof(px_t);
+        const int8_t *qy = (const int8_t *)F.qp_y;
+        const int a = gld<int8_t>(qy + (xp >> F.min_cb_log2) + (yp >> F.min_cb_log2) * F.min_cb_width);
+        const int b = gld<int8_t>(qy + (x >> F.min_cb_log2) + (y >> F.min_cb_log2) * F.min_cb_width);
+        const int len_p = gld<uint8_t>((const uint8_t *)F.max_len_p + tu), len_q = gld<uint8_t>((const uint8_t *)F.max_len_q + tu);
+        const int beta_offset = gld<int8_t>(dbp), tc_offset = gld<int8_t>(dbp + 3);
+        int qp = (a + b + 1) >> 1;
+        if (F.ladf_enabled) {
+            // lf.ladf_level (vvc_filter_template.c:788-803) and the interval search of get_qp_y (:840-846)
+            const int level = (ld_px<BD>(pix, -xs) + ld_px<BD>(pix, -xs + 3 * ys) + ld_px<BD>(pix, 0) + ld_px<BD>(pix, 3 * ys)) >> 2;
+            int qp_offset = F.ladf_lowest_qp_offset;
+            bool go = true;                              // (no break: the loop must unroll so that the table indices are constants)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                go = go && k < F.num_ladf_intervals - 1 && level > F.ladf_lower_bound[k + 1];
+                if (go)
+                    qp_offset = F.ladf_qp_offset[k];
+            }
+            qp += qp_offset;
+        }
+        const int beta = gld<uint8_t>(kBetaTable + clip3(qp + beta_offset, 0, 63));
+        const int tc = gld<uint16_t>(kTcTable + clip3(qp + 2 * (bs - 1) + (tc_offset & -2), 0, 65));
+        deblock_luma_seg<BD>(pix, xs, ys, tc, beta, 0, 0, len_p, len_q, hor_ctu_edge);
+        return;
+    }
+    const int8_t *qc = (const int8_t *)(c == 1 ? F.qp_c[0] : F.qp_c[1]);
+    const uint8_t *tbs = (const uint8_t *)F.tb_size_c;
     for (int seg = t & 1; seg < nseg; seg += 2) {
         const int x = vertical ? e : u + 4 * seg, y = vertical ? u + 4 * seg : e;
         if (vertical ? y >= F.height : x >= F.width)
@@ -805,45 +847,19 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
         const int xp = x - vertical, yp = y - !vertical;
         const int tup = (yp >> 2) * F.min_tu_width + (xp >> 2);
         uint8_t *pix = plane + row_off(y >> vs, stride) + (x >> hs) * (int)sizeof(px_t);
-        int qp, len_p, len_q;
-        if (!c) {
-            const int8_t *qy = (const int8_t *)F.qp_y;
-            const int a = gld<int8_t>(qy + (xp >> F.min_cb_log2) + (yp >> F.min_cb_log2) * F.min_cb_width);
-            const int b = gld<int8_t>(qy + (x >> F.min_cb_log2) + (y >> F.min_cb_log2) * F.min_cb_width);
-            qp = (a + b + 1) >> 1;
-            if (F.ladf_enabled) {
-                // lf.ladf_level (vvc_filter_template.c:788-803) and the interval search of get_qp_y (:840-846)
-                const int level = (ld_px<BD>(pix, -xs) + ld_px<BD>(pix, -xs + 3 * ys) + ld_px<BD>(pix, 0) + ld_px<BD>(pix, 3 * ys)) >> 2;
-                int qp_offset = F.ladf_lowest_qp_offset;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k >= F.num_ladf_intervals - 1 || level <= F.ladf_lower_bound[k + 1])
-                        break;
-                    qp_offset = F.ladf_qp_offset[k];
-                }
-                qp += qp_offset;
-            }
-            len_p = gld<uint8_t>((const uint8_t *)F.max_len_p + tu);
-            len_q = gld<uint8_t>((const uint8_t *)F.max_len_q + tu);
+        const int qp = (gld<int8_t>(qc + tup) + gld<int8_t>(qc + tu) - 2 * F.qp_bd_offset + 1) >> 1;
+        const int size_p = gld<uint8_t>(tbs + tup), size_q = gld<uint8_t>(tbs + tu);
+        int len_p, len_q;
+        if (size_p >= 8 && size_q >= 8) {
+            len_q = 3;
+            len_p = hor_ctu_edge ? 1 : 3;
         } else {
-            const int8_t *qc = (const int8_t *)F.qp_c[c - 1];
-            qp = (gld<int8_t>(qc + tup) + gld<int8_t>(qc + tu) - 2 * F.qp_bd_offset + 1) >> 1;
-            const uint8_t *tbs = (const uint8_t *)F.tb_size_c;
-            const int size_p = gld<uint8_t>(tbs + tup), size_q = gld<uint8_t>(tbs + tu);
-            if (size_p >= 8 && size_q >= 8) {
-                len_q = 3;
-                len_p = hor_ctu_edge ? 1 : 3;
-            } else {
-                len_p = len_q = bs == 2;
-            }
+            len_p = len_q = bs == 2;
         }
         const int beta_offset = gld<int8_t>(dbp + c), tc_offset = gld<int8_t>(dbp + 3 + c);
         const int beta = gld<uint8_t>(kBetaTable + clip3(qp + beta_offset, 0, 63));
         const int tc = gld<uint16_t>(kTcTable + clip3(qp + 2 * (bs - 1) + (tc_offset & -2), 0, 65));
-        if (!c)
-            deblock_luma_seg<BD>(pix, xs, ys, tc, beta, 0, 0, len_p, len_q, hor_ctu_edge);
-        else
-            deblock_chroma_seg<BD>(pix, xs, ys, lines, tc, beta, 0, 0, len_p, len_q);
+        deblock_chroma_seg<BD>(pix, xs, ys, lines, tc, beta, 0, 0, len_p, len_q);
     }
 }
 
