@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
-SAO_TABLES = False             # --sao-tables: SAO through the stage driver (parameters derived on the device from per-CTB tables)
-DEBLOCK_JOBS = True            # --deblock-tables switches to the stage driver that derives every edge's parameters from side tables
+SAO_TABLES = True              # SAO through the stage driver (parameters derived on the device from per-CTB tables); --sao-jobs: host-built jobs
+DEBLOCK_JOBS = False           # deblocking through the stage driver (edge parameters derived from side tables); --deblock-jobs: host-built jobs
 AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -602,9 +602,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
-    ap.add_argument("--sao-tables", action="store_true", help="SAO through vvc355_sao_frame_pass (per-CTB tables) instead of host-built jobs")
-    ap.add_argument("--deblock-tables", action="store_true",
-                    help="profiling aid: deblock through vvc355_deblock_frame_pass (parameters derived on the device from side tables)")
+    ap.add_argument("--sao-jobs", action="store_true", help="profiling aid: SAO from host-built per-CTB jobs (vvc355_sao_ctb_batch) instead of the stage driver")
+    ap.add_argument("--deblock-jobs", action="store_true",
+                    help="profiling aid: deblock from host-built edge jobs (vvc355_deblock_batch) instead of the stage driver")
     ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     return ap.parse_args()
@@ -613,8 +613,8 @@ def parse_args():
 def main():
     args = parse_args()
     global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES
-    SAO_TABLES = args.sao_tables
-    DEBLOCK_JOBS = not args.deblock_tables
+    SAO_TABLES = not args.sao_jobs
+    DEBLOCK_JOBS = args.deblock_jobs
     MC_TOOLS = args.mc_tools & 3
     AFFINE_FRAC = args.affine_frac
     import torch
@@ -692,7 +692,7 @@ def main():
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
                             f"(80 % bi-pred inter CTUs, 20 % intra), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and DEBLOCK_JOBS else ["PROFILING RUN: --mc-tools / --only / --affine-frac / --deblock-tables change the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and SAO_TABLES and not DEBLOCK_JOBS else ["PROFILING RUN: --mc-tools / --only / --affine-frac / --sao-jobs / --deblock-jobs change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {

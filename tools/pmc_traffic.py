@@ -20,9 +20,9 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "intra_pred": "intra_pred_kernel",
     "dequant_itx_add_residual": "itx_shape_kernel",
     "lmcs_inverse_luma": "lmcs_kernel",
-    "deblock_vertical": "deblock_kernel",       # first deblock launch of a step
-    "deblock_horizontal": "deblock_kernel",     # second one
-    "sao": "sao_vec_kernel",
+    "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
+    "deblock_horizontal": "deblock_frame_kernel",   # second one
+    "sao": "sao_frame_kernel",
     "alf_luma_fused": "alf_luma_kernel",
     "alf_chroma": "alf_chroma_kernel",
     "alf_cc": "alf_cc_kernel",
@@ -36,7 +36,7 @@ def per_stage(directory, counter, n_passes):
     out = {}
     for stage, pat in STAGES.items():
         sel = [r for r in rows if pat in r["Kernel_Name"]]
-        if pat == "deblock_kernel":
+        if pat == "deblock_frame_kernel":
             sel = sel[0::2] if stage == "deblock_vertical" else sel[1::2]
         out[stage] = sum(float(r["Counter_Value"]) for r in sel) / n_passes
     return out
