@@ -462,6 +462,7 @@ def build_chain(lib, torch, fr):
         k["src_stride"] = fr.pitch(sao[0])
         k["coeff"] = ptr(cc_coeff) + rng.integers(0, 8, size=len(x0)) * 16
         k["w"], k["h"], k["vb_pos"], k["hs"], k["vs"] = cw, chh, CTB - 4, 1, 1
+        k["ext_l"] = k["ext_t"] = k["ext_r"] = k["ext_b"] = 3
         # CC-ALF reads one luma sample around the co-located position: keep the outermost chroma ring of the picture out
         inner = (x0 > 0) & (y0 > 0) & (x0 + cw < w) & (y0 + chh < h)
         ccj.append(k[inner])

@@ -114,6 +114,8 @@ BATCH_SIGNATURES = {
     "affine_batch":     ("v", "pipi"),
     "deblock_frame_pass": ("v", "pipp"),
     "sao_frame_pass":   ("v", "pipp"),
+    "alf_frame_pass":   ("v", "pippp"),
+    "alf_frame_work_bytes": ("z", "i"),
 }
 
 
@@ -251,6 +253,30 @@ class SaoFrame(ctypes.Structure):
         ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32), ("ctb_height", ctypes.c_int32),
         ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("n_comp", ctypes.c_uint8),
         ("lfase", ctypes.c_uint8), ("no_tile_filter", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+    ]
+
+
+class AlfCtb(ctypes.Structure):
+    """Mirror of vvc355_alf_ctb."""
+    _fields_ = [("ctb_flag", ctypes.c_uint8 * 3), ("filt_set_idx_y", ctypes.c_uint8), ("alt_idx", ctypes.c_uint8 * 2),
+                ("cc_idc", ctypes.c_uint8 * 2)]
+
+
+class AlfSlice(ctypes.Structure):
+    """Mirror of vvc355_alf_slice."""
+    _fields_ = [("luma_coeff", ctypes.c_uint64 * 8), ("luma_clip_idx", ctypes.c_uint64 * 8), ("chroma_coeff", ctypes.c_uint64),
+                ("chroma_clip_idx", ctypes.c_uint64), ("cc_coeff", ctypes.c_uint64 * 2)]
+
+
+class AlfFrame(ctypes.Structure):
+    """Mirror of vvc355_alf_frame (and of the oracle's orc_alf_frame)."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64 * 3), ("src", ctypes.c_uint64 * 3), ("alf", ctypes.c_uint64), ("slices", ctypes.c_uint64),
+        ("slice_idx", ctypes.c_uint64), ("ctb_to_col_bd", ctypes.c_uint64), ("ctb_to_row_bd", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32 * 3), ("src_stride", ctypes.c_int32 * 3),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32), ("ctb_height", ctypes.c_int32),
+        ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("n_comp", ctypes.c_uint8),
+        ("lfase", ctypes.c_uint8), ("lfate", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
     ]
 
 

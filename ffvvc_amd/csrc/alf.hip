@@ -21,6 +21,11 @@ static constexpr int kTileW   = 144;           // LDS row: columns -8 .. 135  (i
 static constexpr int kTileH   = kStripH + 6;   // rows -3 .. 34
 static constexpr int kColOff  = 8;
 
+// fixed filter sets and class maps for the stage driver (generated from the reference's data tables, tools/gen_tables.py)
+#define VVC355_TABLE(type, name, count) __device__ static const type t_##name[count]
+#include "tables.inc"
+#undef VVC355_TABLE
+
 __device__ static const uint8_t kAlfPerm[4][12] = {       // vvc_filter_template.c:387-392
     { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 },
     { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6 },
@@ -367,8 +372,10 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
 
 // ---------------------------------------------------------------------------------------------- CC-ALF kernel
 
-// alf.filter_cc (:223): dst = chroma rectangle (w x h), src = co-located luma; job.coeff = int16[7];
-// job.ext_* unused (the 1-sample luma neighbourhood is read in place, as the reference does from its padded copy).
+// alf.filter_cc (:223): dst = chroma rectangle (w x h), src = co-located luma; job.coeff = int16[7].  The luma neighbourhood
+// (one column left / right, one row above, two below the co-located rectangle) is read in place on the sides whose ext_* is
+// non-zero; on a side with ext_* == 0 the rectangle's own border samples stand in, which is what the reference's padded luma
+// copy holds there (alf_prepare_buffer, vvc_filter.c:1105-1137).
 template <int BD>
 __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__restrict__ jobs)
 {
@@ -379,6 +386,7 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
     int f[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) f[k] = ((const int16_t *)job.coeff)[k];
+    const int row_min = job.ext_t ? -1 : 0, row_max = (job.h << vs) - 1 + (job.ext_b ? 2 : 0);
     if (hs == 1 && (job.w & 3) == 0) {
         // 4:2:0 / 4:2:2: a lane corrects 4 consecutive chroma samples; the 8 co-located luma samples of each of the four rows
         // involved come as one vector (the taps at 2x - 1 / 2x + 1 are the neighbouring halves of its registers), plus the one
@@ -394,12 +402,14 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
             if (ly == vb_pos - 2 || ly == vb_pos + 1) dn2 = 1;
             else if (ly == vb_pos - 1 || ly == vb_pos) up = dn = dn2 = 0;
             const px_t *l0 = (const px_t *)luma + (ptrdiff_t)ly * ls + 2 * x;
+            up = max(ly + up, row_min) - ly; dn = min(ly + dn, row_max) - ly; dn2 = min(ly + dn2, row_max) - ly;
+            const int left = (x | job.ext_l) ? 1 : 0;        // column -1 of the rectangle only where it is readable
             uint32_t ru[4], rc[4], rd[4], r2[4];
             load8_u16<BD>(l0 + up * ls, ru);
             load8_u16<BD>(l0, rc);
             load8_u16<BD>(l0 + dn * ls, rd);
             load8_u16<BD>(l0 + dn2 * ls, r2);
-            const int ec = gld<px_t>(l0 - 1), ed = gld<px_t>(l0 + dn * ls - 1);
+            const int ec = gld<px_t>(l0 - left), ed = gld<px_t>(l0 + dn * ls - left);
             uint8_t *d = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride + x * (int)sizeof(px_t);
             uint32_t cv[2];
             if (BD > 8) { const uint2 q = gld<uint2>(d); cv[0] = q.x; cv[1] = q.y; }
@@ -435,15 +445,18 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
         int up = -1, dn = 1, dn2 = 2;
         if (ly == vb_pos - 2 || ly == vb_pos + 1) dn2 = 1;
         else if (ly == vb_pos - 1 || ly == vb_pos) up = dn = dn2 = 0;
-        const ptrdiff_t o = (ptrdiff_t)ly * ls + (x << hs);
+        up = max(ly + up, row_min) - ly; dn = min(ly + dn, row_max) - ly; dn2 = min(ly + dn2, row_max) - ly;
+        const int lx = x << hs;
+        const int xl = max(lx - 1, job.ext_l ? -1 : 0) - lx, xr = min(lx + 1, (job.w << hs) - 1 + (job.ext_r ? 1 : 0)) - lx;
+        const ptrdiff_t o = (ptrdiff_t)ly * ls + lx;
         const int c = ld_px<BD>(luma, o);
         int sum = 0;
         sum += f[0] * (ld_px<BD>(luma, o + up * ls) - c);
-        sum += f[1] * (ld_px<BD>(luma, o - 1) - c);
-        sum += f[2] * (ld_px<BD>(luma, o + 1) - c);
-        sum += f[3] * (ld_px<BD>(luma, o + dn * ls - 1) - c);
+        sum += f[1] * (ld_px<BD>(luma, o + xl) - c);
+        sum += f[2] * (ld_px<BD>(luma, o + xr) - c);
+        sum += f[3] * (ld_px<BD>(luma, o + dn * ls + xl) - c);
         sum += f[4] * (ld_px<BD>(luma, o + dn * ls) - c);
-        sum += f[5] * (ld_px<BD>(luma, o + dn * ls + 1) - c);
+        sum += f[5] * (ld_px<BD>(luma, o + dn * ls + xr) - c);
         sum += f[6] * (ld_px<BD>(luma, o + dn2 * ls) - c);
         sum = clip3((sum + 64) >> 7, -(1 << (BD - 1)), (1 << (BD - 1)) - 1);
         uint8_t *d = (uint8_t *)job.dst + (ptrdiff_t)y * job.dst_stride;
@@ -464,6 +477,104 @@ __global__ void alf_recon_kernel(int16_t *coeff, int16_t *clip, const int *class
     const int q = clip_idx_set[cls * 12 + idx];
     coeff[i] = coeff_set[class_to_filt[cls] * 12 + idx];
     clip[i] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));
+}
+
+// ---------------------------------------------------------------------------------------------- stage driver
+
+// Zero filter set: a CTB component with alf_ctb_flag off passes through (sum = 0 -> dst = src); also the harmless operand of
+// CC-ALF jobs that are switched off (w = h = 0).
+__device__ static const int16_t kAlfZeroSet[25 * 12] = { 0 };
+
+// ff_vvc_alf_filter (vvc_filter.c:1254-1318) per CTB as a descriptor builder: one lane per CTB writes its luma job, two chroma
+// jobs and two CC-ALF jobs.  edges[] (:1264-1278) become ext_* = 0 (replicate) / 3 (read the neighbour in place).
+template <int BD>
+__global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ fp, int n_ctbs, vvc355_alf_job *luma, vvc355_alf_job *chroma,
+                                 vvc355_alf_job *cc, int16_t *clips)
+{
+    const int rs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rs >= n_ctbs)
+        return;
+    const int px = BD > 8 ? 2 : 1;
+    const int cw = fp->ctb_width, chh = fp->ctb_height, yc = rs / cw, xc = rs - yc * cw;
+    const int ctb_size = 1 << fp->ctb_log2;
+    const vvc355_alf_ctb alf = ((const vvc355_alf_ctb *)fp->alf)[rs];
+    const int16_t *slice = (const int16_t *)fp->slice_idx;
+    const int16_t *col_bd = (const int16_t *)fp->ctb_to_col_bd, *row_bd = (const int16_t *)fp->ctb_to_row_bd;
+    const int me = slice[rs];
+    const vvc355_alf_slice *sl = (const vvc355_alf_slice *)fp->slices + me;
+    bool e_l = xc == 0, e_t = yc == 0, e_r = xc == cw - 1, e_b = yc == chh - 1;
+    if (!fp->lfate) {
+        e_l = e_l || col_bd[xc] == xc;
+        e_t = e_t || row_bd[yc] == yc;
+        e_r = e_r || col_bd[xc] != col_bd[xc + 1];
+        e_b = e_b || row_bd[yc] != row_bd[yc + 1];
+    }
+    if (!fp->lfase) {
+        e_l = e_l || slice[rs - 1] != me;                  // e_* already set where the neighbour does not exist
+        e_t = e_t || slice[rs - cw] != me;
+        e_r = e_r || slice[rs + 1] != me;
+        e_b = e_b || slice[rs + cw] != me;
+    }
+    vvc355_alf_job j = {};
+    j.ext_l = e_l ? 0 : 3; j.ext_t = e_t ? 0 : 3; j.ext_r = e_r ? 0 : 3; j.ext_b = e_b ? 0 : 3;
+    // ---- luma: alf_filter_luma (:1171) with alf_get_coeff_and_clip (:1142)
+    {
+        const int x0 = xc * ctb_size, y0 = yc * ctb_size;
+        j.dst = fp->dst[0] + (uint64_t)y0 * fp->dst_stride[0] + x0 * px;
+        j.src = fp->src[0] + (uint64_t)y0 * fp->src_stride[0] + x0 * px;
+        j.dst_stride = fp->dst_stride[0]; j.src_stride = fp->src_stride[0];
+        j.w = (int16_t)min(fp->width - x0, ctb_size); j.h = (int16_t)min(fp->height - y0, ctb_size);
+        j.vb_pos = (int16_t)(ctb_size - 4);
+        if (!alf.ctb_flag[0]) {
+            j.coeff = (uint64_t)kAlfZeroSet; j.clip = (uint64_t)kAlfZeroSet; j.class_to_filt = (uint64_t)kAlfZeroSet;
+        } else if (alf.filt_set_idx_y < 16) {
+            j.coeff = (uint64_t)t_alf_fix_filt_coeff; j.clip = (uint64_t)kAlfZeroSet;
+            j.class_to_filt = (uint64_t)(t_alf_class_to_filt_map + alf.filt_set_idx_y * 25);
+        } else {
+            j.coeff = sl->luma_coeff[alf.filt_set_idx_y - 16]; j.clip = sl->luma_clip_idx[alf.filt_set_idx_y - 16];
+            j.class_to_filt = (uint64_t)t_alf_aps_class_to_filt_map;
+        }
+        luma[rs] = j;
+    }
+    if (fp->n_comp < 3)
+        return;
+    const int hs = fp->hs, vs = fp->vs;
+    const int x0 = (xc * ctb_size) >> hs, y0 = (yc * ctb_size) >> vs;
+    const int w = min((fp->width >> hs) - x0, ctb_size >> hs), h = min((fp->height >> vs) - y0, ctb_size >> vs);
+    for (int c = 1; c < 3; c++) {
+        // ---- chroma: alf_filter_chroma (:1195)
+        j.dst = fp->dst[c] + (uint64_t)y0 * fp->dst_stride[c] + x0 * px;
+        j.src = fp->src[c] + (uint64_t)y0 * fp->src_stride[c] + x0 * px;
+        j.dst_stride = fp->dst_stride[c]; j.src_stride = fp->src_stride[c];
+        j.w = (int16_t)w; j.h = (int16_t)h; j.vb_pos = (int16_t)((ctb_size >> vs) - 2);
+        j.class_to_filt = 0; j.hs = j.vs = 0;
+        int16_t *cl = clips + (2 * rs + c - 1) * 8;
+        if (alf.ctb_flag[c]) {
+            const int idx = alf.alt_idx[c - 1];
+            const uint8_t *ci = (const uint8_t *)sl->chroma_clip_idx + idx * 6;
+            for (int k = 0; k < 6; k++) {
+                const int q = ci[k];
+                cl[k] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));      // alf_clip_from_idx (:1188)
+            }
+            j.coeff = sl->chroma_coeff + idx * 12;
+        } else {
+            for (int k = 0; k < 6; k++) cl[k] = 0;
+            j.coeff = (uint64_t)kAlfZeroSet;
+        }
+        j.clip = (uint64_t)cl;
+        chroma[2 * rs + c - 1] = j;
+        // ---- CC-ALF: alf_filter_cc (:1212) on the co-located luma
+        const uint64_t cc_set = sl->cc_coeff[c - 1];
+        const bool on = alf.cc_idc[c - 1] && cc_set;
+        j.src = fp->src[0] + (uint64_t)(y0 << vs) * fp->src_stride[0] + (x0 << hs) * px;
+        j.src_stride = fp->src_stride[0];
+        j.coeff = on ? cc_set + (alf.cc_idc[c - 1] - 1) * 14 : (uint64_t)kAlfZeroSet;
+        j.clip = 0;
+        j.w = (int16_t)(on ? w : 0); j.h = (int16_t)(on ? h : 0);
+        j.vb_pos = (int16_t)(ctb_size - 4);
+        j.hs = (int8_t)hs; j.vs = (int8_t)vs;
+        cc[2 * rs + c - 1] = j;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -524,6 +635,32 @@ void vvc355_alf_cc_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, i
     launch_cc(bd, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 
+// ---- ALF stage driver
+size_t vvc355_alf_frame_work_bytes(int n_ctbs)
+{
+    return (size_t)n_ctbs * (5 * sizeof(vvc355_alf_job) + 2 * 8 * sizeof(int16_t));
+}
+
+void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev)
+{
+    const int n = frame_host->ctb_width * frame_host->ctb_height;
+    if (n <= 0) return;
+    if (frame_host->ctb_log2 < 5 || frame_host->ctb_log2 > 7 || (frame_host->width & 7) || (frame_host->height & 7)) {
+        fprintf(stderr, "vvc_mi355: ALF frame %dx%d (CTB log2 %d) outside the driver's domain\n", frame_host->width, frame_host->height, frame_host->ctb_log2);
+        abort();
+    }
+    vvc355_alf_job *luma = (vvc355_alf_job *)work_dev, *chroma = luma + n, *cc = chroma + 2 * n;
+    int16_t *clips = (int16_t *)(cc + 2 * n);
+    hipStream_t st = (hipStream_t)stream;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, clips));
+    HIP_CHECK(hipGetLastError());
+    launch_luma(bd, 1, luma, n, st);
+    if (frame_host->n_comp >= 3) {
+        launch_chroma(bd, chroma, 2 * n, st);
+        launch_cc(bd, cc, 2 * n, st);
+    }
+}
+
 // ---- synchronous per-slot entries (host pointers; reference signatures + leading bd)
 void vvc355_alf_filter_luma(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src, ptrdiff_t src_stride,
                             int width, int height, const int16_t *filter, const int16_t *clip, int vb_pos)
@@ -576,6 +713,7 @@ void vvc355_alf_filter_cc(int bd, uint8_t *dst, ptrdiff_t dst_stride, const uint
     job.coeff = (uint64_t)call.linear(filter, 14, true, false);
     job.w = (int16_t)width; job.h = (int16_t)height; job.vb_pos = (int16_t)vb_pos;
     job.hs = (int8_t)hs; job.vs = (int8_t)vs;
+    job.ext_l = job.ext_r = job.ext_t = job.ext_b = 3;     // the slot's caller hands over a padded buffer
     launch_cc(bd, call.upload(&job, 1), 1, call.stream());
 }
 

@@ -533,6 +533,47 @@ typedef struct vvc355_sao_frame {
 
 void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_dev, const vvc355_sao_frame *frame_host);
 
+/* ------------------------------------------------------------------ ALF stage driver (alf.hip) */
+
+/*
+ * ALF of a whole picture straight from the decoder's per-CTB tables: what ff_vvc_alf_filter (vvc_filter.c:1254-1318) does per
+ * CTB — edges[] from picture borders, tile boundaries and slice indices (:1264-1278; they become the replication flags of
+ * alf_prepare_buffer, :1105-1137), filter-set selection (alf_get_coeff_and_clip :1142-1169, alf_filter_chroma :1195-1210,
+ * alf_filter_cc :1212-1227) — as a device-side builder of the vvc355_alf_job arrays, followed by the three batched kernels.
+ * CTB components with ALF off pass through (a zero filter).  work_dev: DEVICE scratch of vvc355_alf_frame_work_bytes().
+ */
+typedef struct vvc355_alf_ctb {
+    uint8_t ctb_flag[3];          /* alf_ctb_flag[] (ALFParams, vvc_ctu.h:453-459) */
+    uint8_t filt_set_idx_y;       /* AlfCtbFiltSetIdxY: < 16 fixed filter sets, else 16 + index into the slice's luma APS list */
+    uint8_t alt_idx[2];           /* alf_ctb_filter_alt_idx[] */
+    uint8_t cc_idc[2];            /* alf_ctb_cc_cb_idc / _cr_idc */
+} vvc355_alf_ctb;
+
+/* what one slice signals (sh_alf_aps_id_luma[], sh_alf_aps_id_chroma, sh_alf_cc_cb / cr_aps_id resolved to the APS tables) */
+typedef struct vvc355_alf_slice {
+    uint64_t luma_coeff[8];       /* VVCALF.luma_coeff of sh_alf_aps_id_luma[k]: int16 [25][12] */
+    uint64_t luma_clip_idx[8];    /* VVCALF.luma_clip_idx: uint8 [25][12] */
+    uint64_t chroma_coeff;        /* VVCALF.chroma_coeff: int16 [8][6] */
+    uint64_t chroma_clip_idx;     /* VVCALF.chroma_clip_idx: uint8 [8][6] */
+    uint64_t cc_coeff[2];         /* VVCALF.cc_coeff[0 / 1]: int16 [4][7]; 0 = no APS */
+} vvc355_alf_slice;
+
+typedef struct vvc355_alf_frame {
+    uint64_t dst[3], src[3];      /* post- and pre-ALF planes */
+    uint64_t alf;                 /* vvc355_alf_ctb per CTB, raster order (fc->tab.alf) */
+    uint64_t slices;              /* vvc355_alf_slice per slice */
+    uint64_t slice_idx;           /* int16 per CTB (fc->tab.slice_idx) */
+    uint64_t ctb_to_col_bd, ctb_to_row_bd;   /* int16 per CTB column (+1) / row (+1) */
+    int32_t  dst_stride[3], src_stride[3];   /* bytes */
+    int32_t  width, height, ctb_width, ctb_height;
+    uint8_t  ctb_log2, hs, vs, n_comp;
+    uint8_t  lfase, lfate;        /* pps_loop_filter_across_slices / _tiles_enabled_flag */
+    uint8_t  pad_[2];
+} vvc355_alf_frame;
+
+size_t vvc355_alf_frame_work_bytes(int n_ctbs);
+void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev);
+
 #ifdef __cplusplus
 }
 #endif

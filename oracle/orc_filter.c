@@ -835,3 +835,111 @@ ORC_API void orc_sao_frame_pass(int bd, const orc_sao_frame *f)
         }
 #undef SL
 }
+
+
+/* ------------------------------------------------------------------ callers: ALF of a picture
+ *
+ * ff_vvc_alf_filter (vvc_filter.c:1254-1318) per CTB, flattened.  alf_prepare_buffer (:1105-1137) builds the padded source: on
+ * a side whose edges[] flag is set the CTB's own border samples are replicated, otherwise the neighbouring samples are copied —
+ * i.e. per axis, coordinates are clamped to the CTB on flagged sides.  Then alf_filter_luma (:1171-1186: classify,
+ * recon_coeff_and_clip, filter[LUMA]), alf_filter_chroma (:1195-1210), alf_filter_cc (:1212-1227).
+ */
+extern const int16_t orc_tab_alf_fix_filt_coeff[64 * 12];
+extern const uint8_t orc_tab_alf_class_to_filt_map[16 * 25], orc_tab_alf_aps_class_to_filt_map[25];
+
+#define ALF_PAD 8
+#define ALF_PSTRIDE (ORC_PB + 2 * ALF_PAD)
+static void alf_padded(int wide, uint8_t *buf, const uint8_t *plane, ptrdiff_t stride, int x0, int y0, int w, int h, int pw, int ph,
+                       const int *edges, int border)
+{
+    for (int y = -border; y < h + border; y++)
+        for (int x = -border; x < w + border; x++) {
+            int sx = x0 + x, sy = y0 + y;
+            if (x < 0 && edges[0]) sx = x0;
+            if (x >= w && edges[2]) sx = x0 + w - 1;
+            if (y < 0 && edges[1]) sy = y0;
+            if (y >= h && edges[3]) sy = y0 + h - 1;
+            sx = orc_clip3(sx, 0, pw - 1);
+            sy = orc_clip3(sy, 0, ph - 1);
+            orc_st(buf, (ptrdiff_t)(y + ALF_PAD) * ALF_PSTRIDE + x + ALF_PAD, orc_ld(plane, (ptrdiff_t)sy * (stride >> wide) + sx, wide), wide);
+        }
+}
+
+ORC_API void orc_alf_frame_pass(int bd, const orc_alf_frame *f)
+{
+    const int wide = bd > 8, ctb_size = 1 << f->ctb_log2;
+    const orc_alf_ctb *tab = (const orc_alf_ctb *)(uintptr_t)f->alf;
+    const orc_alf_slice *slices = (const orc_alf_slice *)(uintptr_t)f->slices;
+    const int16_t *slice = (const int16_t *)(uintptr_t)f->slice_idx;
+    const int16_t *col_bd = (const int16_t *)(uintptr_t)f->ctb_to_col_bd, *row_bd = (const int16_t *)(uintptr_t)f->ctb_to_row_bd;
+    static _Thread_local uint8_t pad_l[ALF_PSTRIDE * ALF_PSTRIDE * 2], pad_c[ALF_PSTRIDE * ALF_PSTRIDE * 2];
+    static _Thread_local int cls[1024], tr[1024], grad[(ORC_PB + 4) * (ORC_PB + 4)];
+    static _Thread_local int16_t coeff[1024 * 12], clip[1024 * 12];
+    static const uint8_t zero_clip[25 * 12] = { 0 };
+#define SL(x, y) slice[(y) * f->ctb_width + (x)]
+    for (int yc = 0; yc < f->ctb_height; yc++)
+        for (int xc = 0; xc < f->ctb_width; xc++) {
+            const orc_alf_ctb *alf = tab + yc * f->ctb_width + xc;
+            const orc_alf_slice *sl = slices + SL(xc, yc);
+            int edges[4] = { xc == 0, yc == 0, xc == f->ctb_width - 1, yc == f->ctb_height - 1 };
+            if (!f->lfate) {
+                edges[0] = edges[0] || col_bd[xc] == xc;                      /* BOUNDARY_LEFT_TILE */
+                edges[1] = edges[1] || row_bd[yc] == yc;                      /* BOUNDARY_UPPER_TILE */
+                edges[2] = edges[2] || col_bd[xc] != col_bd[xc + 1];
+                edges[3] = edges[3] || row_bd[yc] != row_bd[yc + 1];
+            }
+            if (!f->lfase) {
+                edges[0] = edges[0] || SL(xc, yc) != SL(xc - 1, yc);          /* BOUNDARY_LEFT_SLICE (edges[0] already set at xc == 0) */
+                edges[1] = edges[1] || SL(xc, yc) != SL(xc, yc - 1);
+                edges[2] = edges[2] || SL(xc, yc) != SL(xc + 1, yc);
+                edges[3] = edges[3] || SL(xc, yc) != SL(xc, yc + 1);
+            }
+            for (int c = 0; c < f->n_comp; c++) {
+                const int hs = c ? f->hs : 0, vs = c ? f->vs : 0;
+                const int pw = f->width >> hs, ph = f->height >> vs;
+                const int x0 = (xc * ctb_size) >> hs, y0 = (yc * ctb_size) >> vs;
+                const int w = orc_min(pw - x0, ctb_size >> hs), h = orc_min(ph - y0, ctb_size >> vs);
+                const uint8_t *splane = (const uint8_t *)(uintptr_t)f->src[c];
+                uint8_t *dst = (uint8_t *)(uintptr_t)f->dst[c] + (ptrdiff_t)y0 * f->dst_stride[c] + ((ptrdiff_t)x0 << wide);
+                uint8_t *pad = c ? pad_c : pad_l;
+                const uint8_t *psrc = pad + (((ptrdiff_t)ALF_PAD * ALF_PSTRIDE + ALF_PAD) << wide);
+                const ptrdiff_t pstride = (ptrdiff_t)ALF_PSTRIDE << wide;
+                alf_padded(wide, pad, splane, f->src_stride[c], x0, y0, w, h, pw, ph, edges, c ? 2 : 3);
+                if (!alf->ctb_flag[c]) {
+                    for (int y = 0; y < h; y++)
+                        memcpy(dst + (ptrdiff_t)y * f->dst_stride[c], splane + (ptrdiff_t)(y0 + y) * f->src_stride[c] + ((ptrdiff_t)x0 << wide), (size_t)w << wide);
+                } else if (!c) {
+                    const int16_t *coeff_set;
+                    const uint8_t *clip_idx_set, *class_to_filt;
+                    if (alf->filt_set_idx_y < 16) {
+                        coeff_set = orc_tab_alf_fix_filt_coeff;
+                        clip_idx_set = zero_clip;
+                        class_to_filt = orc_tab_alf_class_to_filt_map + alf->filt_set_idx_y * 25;
+                    } else {
+                        coeff_set = (const int16_t *)(uintptr_t)sl->luma_coeff[alf->filt_set_idx_y - 16];
+                        clip_idx_set = (const uint8_t *)(uintptr_t)sl->luma_clip_idx[alf->filt_set_idx_y - 16];
+                        class_to_filt = orc_tab_alf_aps_class_to_filt_map;
+                    }
+                    const int vb_pos = ctb_size - 4, n = (w / 4) * (h / 4);
+                    orc_alf_classify(bd, cls, tr, psrc, pstride, w, h, vb_pos, grad);
+                    orc_alf_recon_coeff_and_clip(bd, coeff, clip, cls, tr, n, coeff_set, clip_idx_set, class_to_filt);
+                    orc_alf_filter_luma(bd, dst, f->dst_stride[0], psrc, pstride, w, h, coeff, clip, vb_pos);
+                } else {
+                    const int idx = alf->alt_idx[c - 1];
+                    const int16_t *cf = (const int16_t *)(uintptr_t)sl->chroma_coeff + idx * 6;
+                    const uint8_t *ci = (const uint8_t *)(uintptr_t)sl->chroma_clip_idx + idx * 6;
+                    static const int off[4] = { 0, 3, 5, 7 };
+                    int16_t cl[6];
+                    for (int i = 0; i < 6; i++) cl[i] = (int16_t)(1 << (bd - off[ci[i]]));
+                    orc_alf_filter_chroma(bd, dst, f->dst_stride[c], psrc, pstride, w, h, cf, cl, (ctb_size >> vs) - 2);
+                }
+                if (c && alf->cc_idc[c - 1] && sl->cc_coeff[c - 1]) {
+                    /* the luma buffer still holds this CTB's padded luma (component 0 ran first) */
+                    const int16_t *cf = (const int16_t *)(uintptr_t)sl->cc_coeff[c - 1] + (alf->cc_idc[c - 1] - 1) * 7;
+                    const uint8_t *lsrc = pad_l + (((ptrdiff_t)ALF_PAD * ALF_PSTRIDE + ALF_PAD) << wide);
+                    orc_alf_filter_cc(bd, dst, f->dst_stride[c], lsrc, pstride, w, h, hs, vs, cf, ctb_size - 4);
+                }
+            }
+        }
+#undef SL
+}

@@ -173,6 +173,37 @@ typedef struct orc_sao_frame {
 } orc_sao_frame;
 void orc_sao_frame_pass(int bd, const orc_sao_frame *f);
 
+/* ---- ALF of a picture from the decoder's per-CTB tables (orc_filter.c, "ff_vvc_alf_filter"); layouts as in include/vvc_mi355.h ---- */
+typedef struct orc_alf_ctb {
+    uint8_t ctb_flag[3];          /* alf_ctb_flag[] (ALFParams, vvc_ctu.h:453-459) */
+    uint8_t filt_set_idx_y;       /* AlfCtbFiltSetIdxY: < 16 fixed filter sets, else 16 + index into the slice's luma APS list */
+    uint8_t alt_idx[2];           /* alf_ctb_filter_alt_idx[] */
+    uint8_t cc_idc[2];            /* alf_ctb_cc_cb_idc / _cr_idc */
+} orc_alf_ctb;
+
+/* what one slice signals (sh_alf_aps_id_luma[], sh_alf_aps_id_chroma, sh_alf_cc_cb / cr_aps_id resolved to the APS tables) */
+typedef struct orc_alf_slice {
+    uint64_t luma_coeff[8];       /* VVCALF.luma_coeff of sh_alf_aps_id_luma[k]: int16 [25][12] */
+    uint64_t luma_clip_idx[8];    /* VVCALF.luma_clip_idx: uint8 [25][12] */
+    uint64_t chroma_coeff;        /* VVCALF.chroma_coeff: int16 [8][6] */
+    uint64_t chroma_clip_idx;     /* VVCALF.chroma_clip_idx: uint8 [8][6] */
+    uint64_t cc_coeff[2];         /* VVCALF.cc_coeff[0 / 1]: int16 [4][7]; 0 = no APS */
+} orc_alf_slice;
+
+typedef struct orc_alf_frame {
+    uint64_t dst[3], src[3];      /* post- and pre-ALF planes */
+    uint64_t alf;                 /* orc_alf_ctb per CTB, raster order (fc->tab.alf) */
+    uint64_t slices;              /* orc_alf_slice per slice */
+    uint64_t slice_idx;           /* int16 per CTB (fc->tab.slice_idx) */
+    uint64_t ctb_to_col_bd, ctb_to_row_bd;   /* int16 per CTB column (+1) / row (+1) */
+    int32_t  dst_stride[3], src_stride[3];   /* bytes */
+    int32_t  width, height, ctb_width, ctb_height;
+    uint8_t  ctb_log2, hs, vs, n_comp;
+    uint8_t  lfase, lfate;        /* pps_loop_filter_across_slices / _tiles_enabled_flag */
+    uint8_t  pad_[2];
+} orc_alf_frame;
+void orc_alf_frame_pass(int bd, const orc_alf_frame *f);
+
 typedef struct orc_intra_job {
     uint64_t plane;
     int32_t  stride;

@@ -40,3 +40,4 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.DequantJob) == 32
     assert ctypes.sizeof(abi.BipredJob) == 96 and ctypes.sizeof(abi.BipredResult) == 32
     assert ctypes.sizeof(abi.AffineJob) == 88
+    assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136

@@ -113,6 +113,7 @@ def test_alf_chroma_and_cc_frame(dev, orc, bd):
         k.src, k.src_stride = d_luma.ptr + (2 * y0 + 8) * lpitch + (2 * x0 + 8) * isz, lpitch
         k.coeff = d_f[i % len(filt)][2].ptr
         k.w, k.h, k.vb_pos, k.hs, k.vs = w, h, 2 * ctb - 4, 1, 1
+        k.ext_l = k.ext_t = k.ext_r = k.ext_b = 3             # the luma picture carries its apron: read in place
     d_cj, d_ccj = batch.jobs_to_device(cj), batch.jobs_to_device(ccj)
     dev.vvc355_alf_chroma_batch(None, bd, d_cj.ptr, len(ctbs))
     dev.vvc355_alf_cc_batch(None, bd, d_ccj.ptr, len(ctbs))

@@ -271,3 +271,61 @@ def test_affine_without_refinement_is_plain_prediction(orc, bd):
     orc.orc_affine_block(bd, ctypes.byref(j))
     yy, xx = np.clip(np.arange(4) + 8 + 3, 0, ph - 1), np.clip(np.arange(4) + 4 - 20, 0, pw - 1)
     assert np.array_equal(dst, ref[0][yy][:, xx])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_alf_frame_pass_matches_slot_chain_on_one_ctb(orc, bd):
+    """orc_alf_frame_pass (ff_vvc_alf_filter restated, vvc_filter.c:1254-1318) on a one-CTB picture equals the slot functions
+    chained by hand on an edge-replicated copy (all four edges[] set); a CTB with every flag off passes through."""
+    from ffvvc_amd import abi
+    orc.orc_alf_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.AlfFrame)]
+    orc.orc_alf_frame_pass.restype = None
+    rng = np.random.default_rng(0xA1F + bd)
+    w, h, isz = 64, 48, (1 if bd == 8 else 2)
+    dims = [(w, h), (w // 2, h // 2), (w // 2, h // 2)]
+    src = [rand_pixels(rng, (d[1], d[0]), bd) for d in dims]
+    coeff = rng.integers(-40, 40, size=(25, 12)).astype(np.int16)
+    clipi = rng.integers(0, 4, size=(25, 12)).astype(np.uint8)
+    ccoef = rng.integers(-48, 48, size=(8, 6)).astype(np.int16)
+    cclip = rng.integers(0, 4, size=(8, 6)).astype(np.uint8)
+    cc = rng.integers(-32, 32, size=(4, 7)).astype(np.int16)
+    sl = abi.AlfSlice()
+    sl.luma_coeff[1], sl.luma_clip_idx[1] = P(coeff), P(clipi)
+    sl.chroma_coeff, sl.chroma_clip_idx, sl.cc_coeff[0], sl.cc_coeff[1] = P(ccoef), P(cclip), P(cc), 0
+    slice_idx, col_bd, row_bd = np.zeros(1, np.int16), np.array([0, 1], np.int16), np.array([0, 1], np.int16)
+    for on in (0, 1):
+        tab = abi.AlfCtb()
+        tab.ctb_flag[0] = tab.ctb_flag[1] = tab.ctb_flag[2] = on
+        tab.filt_set_idx_y, tab.alt_idx[0], tab.alt_idx[1] = 17, 3, 5
+        tab.cc_idc[0], tab.cc_idc[1] = 2 * on, 1 * on           # Cr has no CC APS: stays off
+        got = [np.full_like(p, 7) for p in src]
+        f = abi.AlfFrame()
+        for c in range(3):
+            f.dst[c], f.src[c], f.dst_stride[c], f.src_stride[c] = P(got[c]), P(src[c]), dims[c][0] * isz, dims[c][0] * isz
+        f.alf, f.slices, f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = ctypes.addressof(tab), ctypes.addressof(sl), P(slice_idx), P(col_bd), P(row_bd)
+        f.width, f.height, f.ctb_width, f.ctb_height, f.ctb_log2, f.hs, f.vs, f.n_comp = w, h, 1, 1, 6, 1, 1, 3
+        f.lfase = f.lfate = 1
+        orc.orc_alf_frame_pass(bd, ctypes.byref(f))
+        if not on:
+            assert all(np.array_equal(got[c], src[c]) for c in range(3))
+            continue
+        pad = [np.pad(p, 8, mode="edge") for p in src]
+        pw = [p.shape[1] for p in pad]
+        want = [np.zeros_like(p) for p in src]
+        nblk = (w // 4) * (h // 4)
+        cls, tr, grad = np.zeros(nblk, np.int32), np.zeros(nblk, np.int32), np.zeros((h + 8) * (w + 8), np.int32)
+        cf, cl = np.zeros((nblk, 12), np.int16), np.zeros((nblk, 12), np.int16)
+        c2f = np.ctypeslib.as_array((ctypes.c_uint8 * 25).in_dll(orc, "orc_tab_alf_aps_class_to_filt_map"))
+        orc.orc_alf_classify(bd, P(cls), P(tr), P(pad[0], 8 * pw[0] + 8), pw[0] * isz, w, h, 60, P(grad))
+        orc.orc_alf_recon_coeff_and_clip(bd, P(cf), P(cl), P(cls), P(tr), nblk, P(coeff), P(clipi), P(c2f))
+        orc.orc_alf_filter_luma(bd, P(want[0]), w * isz, P(pad[0], 8 * pw[0] + 8), pw[0] * isz, w, h, P(cf), P(cl), 60)
+        clipv = np.array([1 << bd, 1 << (bd - 3), 1 << (bd - 5), 1 << (bd - 7)], np.int16)
+        for c in (1, 2):
+            alt = tab.alt_idx[c - 1]
+            cv = clipv[cclip[alt]].copy()
+            orc.orc_alf_filter_chroma(bd, P(want[c]), dims[c][0] * isz, P(pad[c], 8 * pw[c] + 8), pw[c] * isz, dims[c][0], dims[c][1],
+                                      P(ccoef, alt * 6), P(cv), 30)
+        orc.orc_alf_filter_cc(bd, P(want[1]), dims[1][0] * isz, P(pad[0], 8 * pw[0] + 8), pw[0] * isz, dims[1][0], dims[1][1], 1, 1,
+                              P(cc, 7), 60)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), f"component {c}"
