@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+ALF_TABLES = True              # ALF through the stage driver (job descriptors built on the device from ALFParams / APS tables); --alf-jobs: host-built jobs
 SAO_TABLES = True              # SAO through the stage driver (parameters derived on the device from per-CTB tables); --sao-jobs: host-built jobs
 DEBLOCK_JOBS = False           # deblocking through the stage driver (edge parameters derived from side tables); --deblock-jobs: host-built jobs
 AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
@@ -422,6 +423,42 @@ def build_chain(lib, torch, fr):
         chain.append(Stage("sao", f"sao_frame_kernel<{bd}>", lambda st: lib.vvc355_sao_frame_pass(st, bd, ptr(d_sf), ctypes.addressof(sf)),
                            frame_bytes * 2))
 
+    if ALF_TABLES:
+        # ------------------------------------------------------------ ALF through the stage driver: per-CTB ALFParams + APS tables in,
+        # job descriptors built on the device, luma (classify + gather + 7x7 diamond fused), chroma (5x5) and CC-ALF over the
+        # WHOLE picture (every CTB has all three flags on; luma filter sets split between the fixed sets and two APSs)
+        aps_l = alf_filter_sets(rng, 2)
+        d_aps_l = [tuple(fr.upload(a) for a in s[:2]) for s in aps_l]
+        d_cco = fr.upload(rng.integers(-64, 64, size=(8, 6)).astype(np.int16))
+        d_ccl = fr.upload(rng.integers(0, 4, size=(8, 6)).astype(np.uint8))
+        d_ccc = [fr.upload(rng.integers(-32, 32, size=(4, 7)).astype(np.int16)) for _ in range(2)]
+        atab = batch.job_array(abi.AlfCtb, fr.n_ctus)
+        atab["ctb_flag"][:] = 1
+        atab["filt_set_idx_y"] = rng.integers(0, 18, size=fr.n_ctus)
+        atab["alt_idx"] = rng.integers(0, 8, size=(fr.n_ctus, 2))
+        atab["cc_idc"] = rng.integers(1, 5, size=(fr.n_ctus, 2))
+        asl = abi.AlfSlice()
+        for k in range(2):
+            asl.luma_coeff[k], asl.luma_clip_idx[k] = ptr(d_aps_l[k][0]), ptr(d_aps_l[k][1])
+        asl.chroma_coeff, asl.chroma_clip_idx, asl.cc_coeff[0], asl.cc_coeff[1] = ptr(d_cco), ptr(d_ccl), ptr(d_ccc[0]), ptr(d_ccc[1])
+        d_atab, d_asl = fr.upload(atab.view(np.uint8)), fr.upload(np.frombuffer(bytes(asl), np.uint8))
+        d_aslice = fr.upload(np.zeros(fr.n_ctus, np.int16))
+        d_acol, d_arow = fr.upload(np.zeros(fr.ncx + 1, np.int16)), fr.upload(np.zeros(fr.ncy + 1, np.int16))
+        af = abi.AlfFrame()
+        for c in range(3):
+            af.dst[c], af.src[c], af.dst_stride[c], af.src_stride[c] = ptr(out[c]), ptr(sao[c]), fr.pitch(out[c]), fr.pitch(sao[c])
+        af.alf, af.slices, af.slice_idx, af.ctb_to_col_bd, af.ctb_to_row_bd = ptr(d_atab), ptr(d_asl), ptr(d_aslice), ptr(d_acol), ptr(d_arow)
+        af.width, af.height, af.ctb_width, af.ctb_height = fr.width, fr.height, fr.ncx, fr.ncy
+        af.ctb_log2, af.hs, af.vs, af.n_comp, af.lfase, af.lfate = 7, 1, 1, 3, 1, 1
+        d_af = fr.upload(np.frombuffer(bytes(af), np.uint8))
+        d_awork = fr.upload(np.zeros(lib.vvc355_alf_frame_work_bytes(fr.n_ctus), np.uint8))
+        fr.keep.append(af)
+        chroma_bytes = 2 * fr.dims[1][0] * fr.dims[1][1] * isz
+        chain.append(Stage("alf", f"alf_luma_kernel<{bd}, 1> + alf_chroma_kernel<{bd}> + alf_cc_kernel<{bd}> (+ alf_build_kernel)",
+                           lambda st: lib.vvc355_alf_frame_pass(st, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork)),
+                           fr.width * fr.height * isz * 2 + chroma_bytes * 2 + chroma_bytes * 2 + fr.width * fr.height * isz))
+        return chain
+
     # ---------------------------------------------------------------- ALF luma: classify + coefficient gather + 7x7 diamond, fused
     sets = alf_filter_sets(rng, 8)
     d_sets = [tuple(fr.upload(a) for a in s) for s in sets]
@@ -603,6 +640,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
+    ap.add_argument("--alf-jobs", action="store_true", help="profiling aid: ALF from host-built per-CTB jobs (three batch launches, CC-ALF without the outermost CTB ring) instead of the stage driver")
     ap.add_argument("--sao-jobs", action="store_true", help="profiling aid: SAO from host-built per-CTB jobs (vvc355_sao_ctb_batch) instead of the stage driver")
     ap.add_argument("--deblock-jobs", action="store_true",
                     help="profiling aid: deblock from host-built edge jobs (vvc355_deblock_batch) instead of the stage driver")
@@ -613,8 +651,9 @@ def parse_args():
 
 def main():
     args = parse_args()
-    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES
+    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES
     SAO_TABLES = not args.sao_jobs
+    ALF_TABLES = not args.alf_jobs
     DEBLOCK_JOBS = args.deblock_jobs
     MC_TOOLS = args.mc_tools & 3
     AFFINE_FRAC = args.affine_frac
@@ -693,7 +732,7 @@ def main():
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
                             f"(80 % bi-pred inter CTUs, 20 % intra), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and SAO_TABLES and not DEBLOCK_JOBS else ["PROFILING RUN: --mc-tools / --only / --affine-frac / --sao-jobs / --deblock-jobs change the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS else ["PROFILING RUN: --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {

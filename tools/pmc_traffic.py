@@ -23,9 +23,7 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
     "deblock_horizontal": "deblock_frame_kernel",   # second one
     "sao": "sao_frame_kernel",
-    "alf_luma_fused": "alf_luma_kernel",
-    "alf_chroma": "alf_chroma_kernel",
-    "alf_cc": "alf_cc_kernel",
+    "alf": "alf_",                              # the stage driver's four kernels: build, luma, chroma, cc
 }
 
 
