@@ -161,12 +161,12 @@ def build_chain(lib, torch, fr):
     n_bl, n_bc = len(luma_jobs), len(chroma_jobs)
     inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)
 
-    def launch_bipred(st):
-        lib.vvc355_bipred_batch(st, bd, ptr(d_bl), n_bl)          # luma: refines the motion, writes the records
-        lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc)   # chroma of both planes at the refined motion
-
-    chain.append(Stage("inter_pred_bi_dmvr_bdof", f"bipred_kernel<{bd}>", launch_bipred,
-                       inter_samples * 3 * isz))            # two reference samples read + one sample written
+    # luma refines the motion (DMVR) and writes the records; chroma of both planes follows at the refined motion.
+    # algorithmic bytes: two reference samples read + one sample written
+    chain.append(Stage("inter_pred_luma_dmvr_bdof", f"bipred_kernel<{bd}, true>", lambda st: lib.vvc355_bipred_batch(st, bd, ptr(d_bl), n_bl),
+                       n_blk * bs * bs * 3 * isz))
+    chain.append(Stage("inter_pred_chroma", f"bipred_chroma_pair_kernel<{bd}>", lambda st: lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc),
+                       n_blk * 2 * (bs // 2) ** 2 * 3 * isz))
 
     if len(xa0):
         # affine CTUs: every 16x16 area = 16 luma sub-blocks of 4x4 (own motion, PROF on both lists) + its 8x8 chroma blocks

@@ -221,8 +221,9 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
     // fused mode: the CTB's filter set, expanded for the 4 transposes: [transpose][class][tap] = coeff | clip << 16
     __shared__ __attribute__((aligned(16))) uint32_t ftab[MODE == 1 ? 4 * 25 * 12 : 4];
-    const vvc355_alf_job job = jobs[blockIdx.x >> 2];      // (scalar load_uniform measured 6 % slower here: this kernel is VALU-bound and register-tight)
-    const int y_base = (blockIdx.x & 3) * kStripH;
+    const int wg = xcd_chunked(blockIdx.x, gridDim.x);       // an XCD's L2 sees a contiguous run of CTBs (shared aprons)
+    const vvc355_alf_job job = jobs[wg >> 2];      // (scalar load_uniform measured 6 % slower here: this kernel is VALU-bound and register-tight)
+    const int y_base = (wg & 3) * kStripH;
     if (y_base >= job.h)
         return;
     const int rows = min(kStripH, job.h - y_base);
@@ -316,8 +317,9 @@ template <int BD>
 __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *__restrict__ jobs)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
-    const vvc355_alf_job job = load_uniform(jobs + (blockIdx.x >> 2));
-    const int y_base = (blockIdx.x & 3) * kStripH;
+    const int wg = xcd_chunked(blockIdx.x, gridDim.x);
+    const vvc355_alf_job job = load_uniform(jobs + (wg >> 2));
+    const int y_base = (wg & 3) * kStripH;
     if (y_base >= job.h)
         return;
     const int rows = min(kStripH, job.h - y_base);
@@ -379,7 +381,9 @@ __global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *_
 template <int BD>
 __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__restrict__ jobs)
 {
-    const vvc355_alf_job job = load_uniform(jobs + (blockIdx.y));
+    const int lin = xcd_chunked(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int by = lin / (int)gridDim.x, bx = lin - by * (int)gridDim.x;
+    const vvc355_alf_job job = load_uniform(jobs + by);
     const int hs = job.hs, vs = job.vs, vb_pos = job.vb_pos;
     const uint8_t *luma = (const uint8_t *)job.src;
     const ptrdiff_t ls = job.src_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
         // sample left of the vector for the two rows that have side taps.  All loads go out before the first use.
         using px_t = typename Px<BD>::type;
         const int wq = job.w >> 2;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < wq * job.h; i += gridDim.x * blockDim.x) {
+        for (int i = bx * blockDim.x + threadIdx.x; i < wq * job.h; i += gridDim.x * blockDim.x) {
             const int y = i / wq, x = (i - y * wq) * 4;
             const int ly = y << vs;
             if (!vs && (ly == vb_pos || ly == vb_pos + 1))
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void alf_cc_kernel(const vvc355_alf_job *__res
         }
         return;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < job.w * job.h; i += gridDim.x * blockDim.x) {
         const int y = i / job.w, x = i - y * job.w;
         const int ly = y << vs;
         if (!vs && (ly == vb_pos || ly == vb_pos + 1))

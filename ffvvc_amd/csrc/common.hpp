@@ -88,6 +88,25 @@ template <int BD> __device__ __forceinline__ void st_px(uint8_t *p, ptrdiff_t i,
     ((VVC355_GLOBAL typename Px<BD>::type *)p)[i] = (typename Px<BD>::type)v;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  xcd_chunked() renumbers workgroup b of n so that every
+// XCD works through one contiguous eighth of the job list: neighbouring jobs — neighbouring blocks of the picture, whose
+// reference windows overlap — then meet in the same L2 instead of being fetched from HBM once per XCD.
+__device__ __forceinline__ int xcd_chunked(int b, int n)
+{
+    const int xcd = b & 7, idx = b >> 3, q = n >> 3, r = n & 7;
+    return xcd * q + min(xcd, r) + idx;
+}
+
+// The same in groups: XCD x takes G consecutive workgroups out of every 8 * G, so the XCDs stay within 8 * G workgroups of each
+// other in the picture (DRAM page locality) while G neighbours share an L2.  The tail that does not fill 8 * G keeps its number.
+__device__ __forceinline__ int xcd_grouped(int b, int n, int G)
+{
+    const int span = 8 * G, sg = b / span, r = b - sg * span;
+    if ((sg + 1) * span > n)
+        return b;
+    return sg * span + (r & 7) * G + (r >> 3);
+}
+
 // dispatch a kernel template on the runtime bit depth
 #define VVC355_BD_DISPATCH(bd, CALL)                         \
     do {                                                     \

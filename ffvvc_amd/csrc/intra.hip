@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
     __shared__ uint16_t arr_all[TBS][4][kEdgeLen];
     __shared__ int scratch_all[TBS][16];
     const int sub = threadIdx.x / NT;
-    const int ji = blockIdx.x * TBS + sub;
+    const int ji = xcd_chunked(blockIdx.x, gridDim.x) * TBS + sub;
     if (ji >= n_jobs)
         return;
     uint16_t (*arr)[kEdgeLen] = arr_all[sub];

@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
     cos_lds[threadIdx.x] = d_tab_dct2_cos[threadIdx.x];
 
     const int sub = threadIdx.x / NT, tid = threadIdx.x % NT;
-    const int ji = blockIdx.x * TBS + sub;
+    const int wg = xcd_chunked(blockIdx.x, gridDim.x);
+    const int ji = wg * TBS + sub;
     const bool valid = ji < n_jobs;
     const vvc355_itx_job job = jobs[valid ? ji : n_jobs - 1];
     const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
         // some block of this workgroup needs the generic arithmetic: redo them all, one after the other, 256 lanes each
         int *gbuf = (int *)lds_raw, *gtmp = gbuf + CAP;
         for (int b = 0; b < TBS; b++) {
-            const int jb = blockIdx.x * TBS + b;
+            const int jb = wg * TBS + b;
             if (jb >= n_jobs)
                 break;
             const vvc355_itx_job jg = jobs[jb];

@@ -219,13 +219,13 @@ __device__ __forceinline__ void sao_edge8(const uint32_t (&c)[4], const uint32_t
 // samples.  A workgroup covers 128 columns x 64 rows (narrower rectangles: fewer lanes across, more rows).  Only rows / lanes that
 // touch the rectangle's outer ring where a border / restore flag is set take the per-sample path of sao_restore_px.
 template <int BD>
-__device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job)
+__device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job, int bx)
 {
     using px_t = typename Px<BD>::type;
     const int w = job.w, h = job.h, type = job.type;
     const int lxl = w > 64 ? 4 : w > 32 ? 3 : w > 16 ? 2 : w > 8 ? 1 : 0;        // log2 of the lanes across
     const int x0 = (threadIdx.x & ((1 << lxl) - 1)) * 8;
-    const int y0 = (blockIdx.x * (256 >> lxl) + (threadIdx.x >> lxl)) * 4;
+    const int y0 = (bx * (256 >> lxl) + (threadIdx.x >> lxl)) * 4;
     if (y0 >= h || x0 >= w)
         return;
     const px_t *src = (const px_t *)job.src;
@@ -343,7 +343,7 @@ template <int BD>
 __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
 {
     const vvc355_sao_job job = load_uniform(jobs + blockIdx.y);
-    sao_vec_body<BD>(job);
+    sao_vec_body<BD>(job, blockIdx.x);
 }
 
 // a[c] for c in 0..2 as selects between the three values: indexing a register copy of a descriptor with a run-time index would
@@ -354,11 +354,16 @@ template <typename T> __device__ __forceinline__ T sel3(int c, const T (&a)[3]) 
 // works on is derived here, on the scalar unit, from the per-CTB tables: picture-border flags (:172-175), unfilterable slice /
 // tile edges (:177-215), type / band position / edge class / offsets of the component.  CTBs without SAO are copied.
 template <int BD>
-__global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *__restrict__ fp)
+__global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *__restrict__ fp, int xg)
 {
     using px_t = typename Px<BD>::type;
     const vvc355_sao_frame F = load_uniform(fp);
-    const int ctb = blockIdx.y / F.n_comp, c = blockIdx.y - ctb * F.n_comp;
+    // XCD-grouped numbering (xg = the workgroups of four CTBs): the lines holding the samples beside a CTB are shared with the
+    // neighbouring CTB, which then sits in the same L2.  (Measured: L2 fetch traffic 177 -> 103 MB per 8K frame, 0.087 -> 0.082 ms;
+    // one contiguous eighth of the picture per XCD was slower, the XCDs then stream from eight distant DRAM regions.)
+    const int lin = xcd_grouped(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, xg);
+    const int by = lin / (int)gridDim.x, bx = lin - by * (int)gridDim.x;
+    const int ctb = by / F.n_comp, c = by - ctb * F.n_comp;
     const int yc = ctb / F.ctb_width, xc = ctb - yc * F.ctb_width;
     const vvc355_sao_ctb P = load_uniform((const vvc355_sao_ctb *)F.sao + ctb);
     const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
     if (type_idx == 0) {
         // SAO not applied: the samples pass through (16-byte vectors where the row allows, else sample by sample)
         const int w = job.w, h = job.h, wv = w >> 3;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < (wv + 1) * h; i += gridDim.x * 256) {
+        for (int i = bx * 256 + threadIdx.x; i < (wv + 1) * h; i += gridDim.x * 256) {
             const int y = i / (wv + 1), xv = i - y * (wv + 1);
             const px_t *sp = (const px_t *)((const uint8_t *)job.src + row_off(y, job.src_stride)) + xv * 8;
             px_t *dp = (px_t *)((uint8_t *)job.dst + row_off(y, job.dst_stride)) + xv * 8;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
         if (!eR && !eB) job.diag_edge[2] = (nl && me != slice[ctb + cw + 1]) || rt || bt;
         if (!eL && !eB) job.diag_edge[3] = (nl && me != slice[ctb + cw - 1]) || lt || bt;
     }
-    sao_vec_body<BD>(job);
+    sao_vec_body<BD>(job, bx);
 }
 
 // ------------------------------------------------------------------------------------------------ deblock
@@ -930,7 +935,7 @@ void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_d
     const int n = F.ctb_width * F.ctb_height * F.n_comp;
     if (n <= 0) return;
     const int ctb = 1 << F.ctb_log2;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_frame_kernel<BD>), dim3((ctb + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, frame_dev));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_frame_kernel<BD>), dim3((ctb + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, frame_dev, 4 * ((ctb + 63) / 64) * F.n_comp));
     HIP_CHECK(hipGetLastError());
 }
 

@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
 {
     __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLds, BipredLdsLight>::type lds_all[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ji = blockIdx.x * 4 + wave;
+    const int ji = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
     if (ji >= n_jobs)
         return;
     // The descriptor is copied dword-wise at a wave-uniform address (scalar loads, issued once); reading its byte / short
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void bipred_chroma_pair_kernel(const vvc355_bi
     __shared__ __attribute__((aligned(16))) BipredLdsLight lds_all[4];
     using px_t = typename Px<BD>::type;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ia = 2 * (blockIdx.x * 4 + wave);
+    const int ia = 2 * (xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave);
     if (ia >= n_jobs)
         return;
     const bool has_b = ia + 1 < n_jobs;

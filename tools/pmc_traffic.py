@@ -16,7 +16,8 @@ import json
 import sys
 
 STAGES = {                      # stage name of bench.py -> substring of the kernel name
-    "inter_pred_bi_dmvr_bdof": "bipred_kernel",
+    "inter_pred_luma_dmvr_bdof": "bipred_kernel",
+    "inter_pred_chroma": "bipred_chroma_pair_kernel",
     "intra_pred": "intra_pred_kernel",
     "dequant_itx_add_residual": "itx_shape_kernel",
     "lmcs_inverse_luma": "lmcs_kernel",
