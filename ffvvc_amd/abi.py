@@ -115,6 +115,7 @@ BATCH_SIGNATURES = {
     "deblock_frame_pass": ("v", "pipp"),
     "sao_frame_pass":   ("v", "pipp"),
     "alf_frame_pass":   ("v", "pippp"),
+    "deblock_bs_pass":  ("v", "ppp"),
     "alf_frame_work_bytes": ("z", "i"),
 }
 
@@ -277,6 +278,29 @@ class AlfFrame(ctypes.Structure):
         ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32), ("ctb_height", ctypes.c_int32),
         ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("n_comp", ctypes.c_uint8),
         ("lfase", ctypes.c_uint8), ("lfate", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+    ]
+
+
+class MvField(ctypes.Structure):
+    """Mirror of vvc355_mvfield (= the reference's MvField, vvc_ctu.h:195-202)."""
+    _fields_ = [("mv", (ctypes.c_int32 * 2) * 2), ("ref_idx", ctypes.c_int8 * 2), ("hpel_if_idx", ctypes.c_uint8),
+                ("bcw_idx", ctypes.c_uint8), ("pred_flag", ctypes.c_uint8), ("ciip_flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2)]
+
+
+class BsFrame(ctypes.Structure):
+    """Mirror of vvc355_bs_frame (and of the oracle's orc_bs_frame)."""
+    _fields_ = [
+        ("mvf", ctypes.c_uint64), ("ref_poc", ctypes.c_uint64), ("slice_idx", ctypes.c_uint64),
+        ("ctb_to_col_bd", ctypes.c_uint64), ("ctb_to_row_bd", ctypes.c_uint64),
+        ("tu_coded_flag", ctypes.c_uint64 * 3), ("tu_joint_cbcr", ctypes.c_uint64), ("pcmf", ctypes.c_uint64 * 2),
+        ("tb_pos_x0", ctypes.c_uint64 * 2), ("tb_pos_y0", ctypes.c_uint64 * 2), ("tb_width", ctypes.c_uint64 * 2), ("tb_height", ctypes.c_uint64 * 2),
+        ("cb_pos_x", ctypes.c_uint64), ("cb_pos_y", ctypes.c_uint64), ("cb_width", ctypes.c_uint64), ("cb_height", ctypes.c_uint64),
+        ("msf", ctypes.c_uint64), ("iaf", ctypes.c_uint64),
+        ("bs", (ctypes.c_uint64 * 3) * 2), ("max_len_p", ctypes.c_uint64 * 2), ("max_len_q", ctypes.c_uint64 * 2),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("min_tu_width", ctypes.c_int32), ("min_pu_width", ctypes.c_int32), ("min_cb_width", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
+        ("ctb_log2", ctypes.c_uint8), ("min_cb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("n_comp", ctypes.c_uint8),
+        ("lfase", ctypes.c_uint8), ("lfate", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
     ]
 
 

@@ -918,6 +918,164 @@ static void slot_deblock(int bd, int dir, int chroma, uint8_t *pix, ptrdiff_t st
     launch_deblock(bd, call.upload(&job, 1), 1, call.stream());
 }
 
+// ---------------------------------------------------------------------------------------------- boundary strengths
+
+// boundary_strength (vvc_filter.c:308-372): the motion rule between two inter blocks.  pc / pn = reference POC lists of the
+// slices the two blocks belong to (int32 [2][32]).
+__device__ __forceinline__ bool mv_far(const int32_t *a, const int32_t *b) { return abs(a[0] - b[0]) >= 8 || abs(a[1] - b[1]) >= 8; }
+
+__device__ __forceinline__ int bs_motion(const vvc355_mvfield &c, const vvc355_mvfield &n, const int *pc, const int *pn)
+{
+    if (c.pred_flag == 3 && n.pred_flag == 3) {
+        const int c0 = gld<int>(pc + c.ref_idx[0]), c1 = gld<int>(pc + 32 + c.ref_idx[1]);
+        const int n0 = gld<int>(pn + n.ref_idx[0]), n1 = gld<int>(pn + 32 + n.ref_idx[1]);
+        if (c0 == n0 && c0 == c1 && n0 == n1)
+            return (mv_far(n.mv[0], c.mv[0]) || mv_far(n.mv[1], c.mv[1])) && (mv_far(n.mv[1], c.mv[0]) || mv_far(n.mv[0], c.mv[1]));
+        if (n0 == c0 && n1 == c1)
+            return mv_far(n.mv[0], c.mv[0]) || mv_far(n.mv[1], c.mv[1]);
+        if (n1 == c0 && n0 == c1)
+            return mv_far(n.mv[1], c.mv[0]) || mv_far(n.mv[0], c.mv[1]);
+        return 1;
+    }
+    if (c.pred_flag != 3 && n.pred_flag != 3) {
+        const bool c_l0 = c.pred_flag & 1, n_l0 = n.pred_flag & 1;
+        const int ra = gld<int>(pc + (c_l0 ? c.ref_idx[0] : 32 + c.ref_idx[1]));
+        const int rb = gld<int>(pn + (n_l0 ? n.ref_idx[0] : 32 + n.ref_idx[1]));
+        if (ra != rb)
+            return 1;
+        const int ax = c_l0 ? c.mv[0][0] : c.mv[1][0], ay = c_l0 ? c.mv[0][1] : c.mv[1][1];
+        const int bx = n_l0 ? n.mv[0][0] : n.mv[1][0], by = n_l0 ? n.mv[0][1] : n.mv[1][1];
+        return abs(ax - bx) >= 8 || abs(ay - by) >= 8;
+    }
+    return 1;
+}
+
+__device__ __forceinline__ vvc355_mvfield ld_mvf(const vvc355_mvfield *p)
+{
+    uint64_t w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i] = gld<uint64_t>((const uint64_t *)p + i);
+    vvc355_mvfield r;
+    __builtin_memcpy(&r, w, 24);
+    return r;
+}
+
+// One lane per 4x4 luma unit; both edge directions (dir 1 = vertical edges: neighbour on the left, dir 0 = horizontal edges:
+// neighbour above).  Gather form of vvc_deblock_bs (vvc_filter.c:756-783): the unit asks which rule of the transform unit
+// covering it wrote its entry in the reference's scatter loops.
+__global__ __launch_bounds__(256) void deblock_bs_kernel(const vvc355_bs_frame *__restrict__ fp)
+{
+    const VVC355_CONST vvc355_bs_frame &F = *(const VVC355_CONST vvc355_bs_frame *)fp;
+    const int mtw = F.min_tu_width, mpw = F.min_pu_width;
+    const int ux = blockIdx.x * 64 + (threadIdx.x & 63), uy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = ux * 4, y = uy * 4;
+    if (x >= F.width || y >= F.height)
+        return;
+    const int off = uy * mtw + ux;
+    const int ctb_log2 = F.ctb_log2, ctb_mask = (1 << ctb_log2) - 1;
+    const vvc355_mvfield *mvf = (const vvc355_mvfield *)F.mvf;
+    const int16_t *slice = (const int16_t *)F.slice_idx;
+    const int ctb = (y >> ctb_log2) * F.ctb_width + (x >> ctb_log2);
+    const int my_slice = gld<int16_t>(slice + ctb);
+    const vvc355_mvfield curr = ld_mvf(mvf + uy * mpw + ux);
+
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+        const int a = dir ? x : y;                              // coordinate across the edge
+        // ---- may the CTB edge this unit sits on be filtered at all? (:498-507, :583-591)
+        bool ctb_edge_off = false;
+        int n_slice = my_slice;
+        if (a > 0 && !(a & ctb_mask)) {
+            const int nctb = dir ? ctb - 1 : ctb - F.ctb_width;
+            n_slice = gld<int16_t>(slice + nctb);
+            const int16_t *bd = (const int16_t *)(dir ? F.ctb_to_col_bd : F.ctb_to_row_bd);
+            const int r = a >> ctb_log2;
+            const bool tile_edge = gld<int16_t>(bd + r) != gld<int16_t>(bd + r - 1);
+            ctb_edge_off = (!F.lfase && n_slice != my_slice) || (!F.lfate && tile_edge);
+        }
+        const int noff = dir ? off - 1 : off - mtw;             // the P-side unit
+        const vvc355_mvfield *np = mvf + (dir ? uy * mpw + ux - 1 : (uy - 1) * mpw + ux);
+        // ---- luma tree
+        int bs = 0, len_p = 0, len_q = 0;
+        {
+            const int tx0 = gld<int>((const int *)F.tb_pos_x0[0] + off), ty0 = gld<int>((const int *)F.tb_pos_y0[0] + off);
+            const int t0 = dir ? tx0 : ty0;                      // the transform unit's origin across the edge
+            const uint8_t *tb_size = (const uint8_t *)(dir ? F.tb_width[0] : F.tb_height[0]);
+            const int tsize = gld<uint8_t>(tb_size + off);
+            const bool is_intra = gld<uint8_t>((const uint8_t *)(mvf + (ty0 >> 2) * mpw + (tx0 >> 2)) + 20) == 0;
+            const int cbo = (ty0 >> F.min_cb_log2) * F.min_cb_width + (tx0 >> F.min_cb_log2);
+            const int cb0 = gld<int>((const int *)(dir ? F.cb_pos_x : F.cb_pos_y) + cbo);
+            const int cb_size = gld<uint8_t>((const uint8_t *)(dir ? F.cb_width : F.cb_height) + cbo);
+            const bool sb_cu = !is_intra && (gld<uint8_t>((const uint8_t *)F.msf + cbo) || gld<uint8_t>((const uint8_t *)F.iaf + cbo));
+            const bool has_sb = sb_cu && cb_size > 8;
+            if (a == t0) {
+                if (a > 0 && !ctb_edge_off) {
+                    // transform-block edge (:509-545)
+                    const vvc355_mvfield neigh = ld_mvf(np);
+                    const uint8_t *cbf = (const uint8_t *)F.tu_coded_flag[0], *pcm = (const uint8_t *)F.pcmf[0];
+                    const int off_c = cb0 - t0;
+                    if (gld<uint8_t>(pcm + noff) && gld<uint8_t>(pcm + off))
+                        bs = 0;
+                    else if (curr.pred_flag == 0 || neigh.pred_flag == 0 || curr.ciip_flag || neigh.ciip_flag)
+                        bs = 2;
+                    else if (gld<uint8_t>(cbf + off) || gld<uint8_t>(cbf + noff))
+                        bs = 1;
+                    else if (off_c && ((off_c & 7) || !has_sb))
+                        bs = 0;
+                    else
+                        bs = bs_motion(curr, neigh, (const int *)F.ref_poc + my_slice * 64, (const int *)F.ref_poc + n_slice * 64);
+                    // derive_max_filter_length_luma (:374-397)
+                    const int size_p = gld<uint8_t>(tb_size + noff);
+                    if (size_p <= 4 || tsize <= 4) {
+                        len_p = len_q = 1;
+                    } else {
+                        len_p = size_p >= 32 ? 7 : 3;
+                        len_q = tsize >= 32 ? 7 : 3;
+                    }
+                    if (has_sb)
+                        len_q = min(5, len_q);
+                    const int px = dir ? x - 1 : x, py = dir ? y : y - 1;
+                    const int cbp = (py >> F.min_cb_log2) * F.min_cb_width + (px >> F.min_cb_log2);
+                    if (gld<uint8_t>((const uint8_t *)F.msf + cbp) || gld<uint8_t>((const uint8_t *)F.iaf + cbp))
+                        len_p = min(5, len_p);
+                }
+            } else if (sb_cu && !((a - cb0) & 7)) {
+                // sub-block edge inside the transform unit (:399-475), both sides in the current slice
+                const vvc355_mvfield neigh = ld_mvf(np);
+                const int *rpl = (const int *)F.ref_poc + my_slice * 64;
+                bs = bs_motion(curr, neigh, rpl, rpl);
+                const int i = a - t0;
+                len_p = len_q = (i == 4 || i == tsize - 4) ? 1 : (i == 8 || i == tsize - 8) ? 2 : 3;
+            }
+        }
+        gst<uint8_t>((uint8_t *)F.bs[dir][0] + off, (uint8_t)bs);
+        gst<uint8_t>((uint8_t *)F.max_len_p[dir] + off, (uint8_t)len_p);
+        gst<uint8_t>((uint8_t *)F.max_len_q[dir] + off, (uint8_t)len_q);
+        if (F.n_comp < 3)
+            continue;
+        // ---- chroma tree (:642-754): transform-block edges on the 8-sample chroma grid only
+        int bs_c[2] = { 0, 0 };
+        {
+            const int t0 = gld<int>((const int *)(dir ? F.tb_pos_x0[1] : F.tb_pos_y0[1]) + off);
+            const int grid = (8 << (dir ? F.hs : F.vs)) - 1;
+            if (a == t0 && a > 0 && !(a & grid) && !ctb_edge_off) {
+                const vvc355_mvfield neigh = ld_mvf(np);
+                const uint8_t *pcm = (const uint8_t *)F.pcmf[1], *jc = (const uint8_t *)F.tu_joint_cbcr;
+                const bool pcmf = gld<uint8_t>(pcm + noff) && gld<uint8_t>(pcm + off);
+                const bool strong = curr.pred_flag == 0 || neigh.pred_flag == 0 || curr.ciip_flag || neigh.ciip_flag;
+                const int joint = gld<uint8_t>(jc + noff) | gld<uint8_t>(jc + off);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint8_t *cbf = (const uint8_t *)F.tu_coded_flag[c + 1];
+                    bs_c[c] = pcmf ? 0 : strong ? 2 : (gld<uint8_t>(cbf + noff) | gld<uint8_t>(cbf + off) | joint) ? 1 : 0;
+                }
+            }
+        }
+        gst<uint8_t>((uint8_t *)F.bs[dir][1] + off, (uint8_t)bs_c[0]);
+        gst<uint8_t>((uint8_t *)F.bs[dir][2] + off, (uint8_t)bs_c[1]);
+    }
+}
+
 } // namespace vvc355
 
 using namespace vvc355;
@@ -927,6 +1085,19 @@ extern "C" {
 void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
     launch_sao(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
+}
+
+void vvc355_deblock_bs_pass(void *stream, const vvc355_bs_frame *frame_dev, const vvc355_bs_frame *frame_host)
+{
+    const vvc355_bs_frame &F = *frame_host;        // host copy: geometry only
+    if (F.width <= 0 || F.height <= 0) return;
+    if ((F.width & 3) || (F.height & 3) || F.min_tu_width < F.width / 4 || F.min_pu_width < F.width / 4) {
+        fprintf(stderr, "vvc_mi355: deblock_bs_pass: %dx%d with table pitches %d / %d outside the driver's domain\n", F.width, F.height, F.min_tu_width, F.min_pu_width);
+        abort();
+    }
+    const int nx = F.width / 4, ny = F.height / 4;
+    hipLaunchKernelGGL(deblock_bs_kernel, dim3((nx + 63) / 64, (ny + 3) / 4), dim3(256), 0, (hipStream_t)stream, frame_dev);
+    HIP_CHECK(hipGetLastError());
 }
 
 void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_dev, const vvc355_sao_frame *frame_host)

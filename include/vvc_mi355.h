@@ -502,6 +502,50 @@ typedef struct vvc355_deblock_frame {
 /* frame_dev: DEVICE address of one descriptor; the launch covers every edge unit of the pass */
 void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame *frame_dev, const vvc355_deblock_frame *frame_host);
 
+/*
+ * Boundary strengths and luma maximum filter lengths of a whole picture, both edge directions in one launch: what
+ * vvc_deblock_bs (vvc_filter.c:756-783) derives per transform unit at the start of ff_vvc_deblock_vertical / _horizontal —
+ * vvc_deblock_bs_luma_vertical / _horizontal (:477-640: transform-block edges, pcm / intra / ciip / cbf rules, the motion rule
+ * boundary_strength :308-372, slice / tile edges that must not be filtered), the sub-block edges of affine / sub-block-merge
+ * coding blocks (:399-475), derive_max_filter_length_luma (:374-397) and the chroma rules (:642-754).  One lane per 4x4 luma
+ * unit GATHERS its entries (the reference scatters per transform unit); every entry of the output tables is written.
+ * The outputs are the bs / max_len inputs of vvc355_deblock_frame_pass.
+ */
+typedef struct vvc355_mvfield {             /* MvField, vvc_ctu.h:195-202 (same layout: 24 bytes) */
+    int32_t mv[2][2];             /* [list][x, y] */
+    int8_t  ref_idx[2];
+    uint8_t hpel_if_idx, bcw_idx;
+    uint8_t pred_flag;            /* PF_INTRA 0, PF_L0 1, PF_L1 2, PF_BI 3 (vvc_ctu.h:216-219) */
+    uint8_t ciip_flag;
+    uint8_t pad_[2];
+} vvc355_mvfield;
+
+typedef struct vvc355_bs_frame {
+    /* inputs: the decoder's side tables (VVCFrameContext.tab, vvcdec.h:122-187), uploaded as they are */
+    uint64_t mvf;                 /* vvc355_mvfield per 4x4 luma unit, row pitch min_pu_width */
+    uint64_t ref_poc;             /* int32 [slice][2][32]: RefPicList.list[] (POCs) of the slice's two lists */
+    uint64_t slice_idx;           /* int16 per CTB */
+    uint64_t ctb_to_col_bd, ctb_to_row_bd;   /* int16 per CTB column (+1) / row (+1) */
+    uint64_t tu_coded_flag[3];    /* uint8 per 4x4 luma unit */
+    uint64_t tu_joint_cbcr;       /* tu_joint_cbcr_residual_flag, uint8 per 4x4 luma unit */
+    uint64_t pcmf[2];             /* uint8 per 4x4 luma unit, [0] luma tree, [1] chroma tree */
+    uint64_t tb_pos_x0[2], tb_pos_y0[2];     /* int32 per 4x4 luma unit, luma coordinates, per tree */
+    uint64_t tb_width[2], tb_height[2];      /* uint8 per 4x4 luma unit, in samples of the component */
+    uint64_t cb_pos_x, cb_pos_y;  /* int32 per minimum coding block (luma tree) */
+    uint64_t cb_width, cb_height; /* uint8 per minimum coding block */
+    uint64_t msf, iaf;            /* MergeSubblockFlag, InterAffineFlag: uint8 per minimum coding block */
+    /* outputs, uint8 per 4x4 luma unit: [0] horizontal edges, [1] vertical edges */
+    uint64_t bs[2][3];            /* fc->tab.horizontal_bs[c] / vertical_bs[c] */
+    uint64_t max_len_p[2], max_len_q[2];     /* fc->tab.horizontal_p / _q, vertical_p / _q */
+    int32_t  width, height;       /* luma picture size */
+    int32_t  min_tu_width, min_pu_width, min_cb_width, ctb_width;
+    uint8_t  ctb_log2, min_cb_log2, hs, vs, n_comp;
+    uint8_t  lfase, lfate;        /* pps_loop_filter_across_slices / _tiles_enabled_flag */
+    uint8_t  pad_;
+} vvc355_bs_frame;
+
+void vvc355_deblock_bs_pass(void *stream, const vvc355_bs_frame *frame_dev, const vvc355_bs_frame *frame_host);
+
 /* ------------------------------------------------------------------ SAO stage driver (loopfilter.hip) */
 
 /*

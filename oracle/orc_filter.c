@@ -943,3 +943,194 @@ ORC_API void orc_alf_frame_pass(int bd, const orc_alf_frame *f)
         }
 #undef SL
 }
+
+/* ------------------------------------------------------------------ callers: boundary strengths of a picture
+ *
+ * vvc_deblock_bs (vvc_filter.c:756-783) for every CTB and both directions, in the reference's own shape: walk the transform
+ * units of each tree, and let each one write the entries of its left / upper edge and of its internal sub-block edges.
+ * dir 1 = vertical edges (vvc_deblock_bs_luma_vertical :477, _chroma_vertical :642, subblock :399),
+ * dir 0 = horizontal edges (:560, :698, :437).  The output tables are cleared first (the decoder clears them per frame).
+ */
+static int bs_mv_far(const int32_t *a, const int32_t *b) { return abs(a[0] - b[0]) >= 8 || abs(a[1] - b[1]) >= 8; }
+
+/* boundary_strength (:308-372); rpl / nrpl = int32 [2][32] POC lists */
+static int bs_boundary_strength(const orc_mvfield *curr, const orc_mvfield *neigh, const int32_t *rpl, const int32_t *nrpl)
+{
+    if (curr->pred_flag == 3 && neigh->pred_flag == 3) {
+        const int c0 = rpl[curr->ref_idx[0]], c1 = rpl[32 + curr->ref_idx[1]];
+        const int n0 = nrpl[neigh->ref_idx[0]], n1 = nrpl[32 + neigh->ref_idx[1]];
+        if (c0 == n0 && c0 == c1 && n0 == n1)
+            return (bs_mv_far(neigh->mv[0], curr->mv[0]) || bs_mv_far(neigh->mv[1], curr->mv[1])) &&
+                   (bs_mv_far(neigh->mv[1], curr->mv[0]) || bs_mv_far(neigh->mv[0], curr->mv[1]));
+        if (n0 == c0 && n1 == c1)
+            return bs_mv_far(neigh->mv[0], curr->mv[0]) || bs_mv_far(neigh->mv[1], curr->mv[1]);
+        if (n1 == c0 && n0 == c1)
+            return bs_mv_far(neigh->mv[1], curr->mv[0]) || bs_mv_far(neigh->mv[0], curr->mv[1]);
+        return 1;
+    }
+    if (curr->pred_flag != 3 && neigh->pred_flag != 3) {
+        const int la = (curr->pred_flag & 1) ? 0 : 1, lb = (neigh->pred_flag & 1) ? 0 : 1;
+        const int ref_a = rpl[la * 32 + curr->ref_idx[la]], ref_b = nrpl[lb * 32 + neigh->ref_idx[lb]];
+        if (ref_a != ref_b)
+            return 1;
+        return bs_mv_far(curr->mv[la], neigh->mv[lb]);
+    }
+    return 1;
+}
+
+typedef struct bs_ctx {
+    const orc_bs_frame *f;
+    const orc_mvfield *mvf;
+    const int32_t *rpl;               /* the current CTU's slice */
+    int left_slice, upper_slice, left_tile, upper_tile;     /* lc->boundary_flags of the current CTU (vvc_ctu.c:2481-2489) */
+    int ctb_x, ctb_y;
+} bs_ctx;
+
+#define BS_U8(p)  ((uint8_t *)(uintptr_t)(p))
+#define BS_I32(p) ((const int32_t *)(uintptr_t)(p))
+#define BS_TU(f, x, y) (((y) >> 2) * (f)->min_tu_width + ((x) >> 2))
+
+static void bs_luma_tu(const bs_ctx *c, int dir, int x0, int y0, int width, int height)
+{
+    const orc_bs_frame *f = c->f;
+    const int mpw = f->min_pu_width;
+    const int is_intra = c->mvf[(y0 >> 2) * mpw + (x0 >> 2)].pred_flag == 0;
+    const int off_q = (y0 >> f->min_cb_log2) * f->min_cb_width + (x0 >> f->min_cb_log2);
+    const int cb_x = BS_I32(f->cb_pos_x)[off_q], cb_y = BS_I32(f->cb_pos_y)[off_q];
+    const int cb_size = dir ? BS_U8(f->cb_width)[off_q] : BS_U8(f->cb_height)[off_q];
+    const int sb_cu = !is_intra && (BS_U8(f->msf)[off_q] || BS_U8(f->iaf)[off_q]);
+    const int has_sb = sb_cu && cb_size > 8;
+    const int a0 = dir ? x0 : y0, along = dir ? height : width, across = dir ? width : height;
+    const int ctb_mask = (1 << f->ctb_log2) - 1;
+    uint8_t *tab_bs = BS_U8(f->bs[dir][0]), *tab_p = BS_U8(f->max_len_p[dir]), *tab_q = BS_U8(f->max_len_q[dir]);
+    const uint8_t *tb_size = dir ? BS_U8(f->tb_width[0]) : BS_U8(f->tb_height[0]);
+
+    int boundary = a0 > 0 && !(a0 & 3);
+    if (boundary && ((!f->lfase && (dir ? c->left_slice : c->upper_slice) && !(a0 & ctb_mask)) ||
+                     (!f->lfate && (dir ? c->left_tile : c->upper_tile) && !(a0 & ctb_mask))))
+        boundary = 0;
+    if (boundary) {
+        /* the neighbour's lists: those of the CTB the P side lies in (ff_vvc_get_ref_list, vvc_refs.c:66) */
+        const int px0 = dir ? x0 - 1 : x0, py0 = dir ? y0 : y0 - 1;
+        const int nslice = ((const int16_t *)(uintptr_t)f->slice_idx)[(py0 >> f->ctb_log2) * f->ctb_width + (px0 >> f->ctb_log2)];
+        const int32_t *nrpl = ((dir ? c->left_slice : c->upper_slice) ? BS_I32(f->ref_poc) + nslice * 64 : c->rpl);
+        for (int i = 0; i < along; i += 4) {
+            const int qx = dir ? x0 : x0 + i, qy = dir ? y0 + i : y0;
+            const int px = dir ? qx - 1 : qx, py = dir ? qy : qy - 1;
+            const orc_mvfield *neigh = &c->mvf[(py >> 2) * mpw + (px >> 2)], *curr = &c->mvf[(qy >> 2) * mpw + (qx >> 2)];
+            const int tq = BS_TU(f, qx, qy), tp = BS_TU(f, px, py);
+            const int off_c = (dir ? cb_x : cb_y) - a0;
+            int bs, len_p, len_q;
+            if (BS_U8(f->pcmf[0])[tp] && BS_U8(f->pcmf[0])[tq])
+                bs = 0;
+            else if (curr->pred_flag == 0 || neigh->pred_flag == 0 || curr->ciip_flag || neigh->ciip_flag)
+                bs = 2;
+            else if (BS_U8(f->tu_coded_flag[0])[tq] || BS_U8(f->tu_coded_flag[0])[tp])
+                bs = 1;
+            else if (off_c && ((off_c % 8) || !has_sb))
+                bs = 0;
+            else
+                bs = bs_boundary_strength(curr, neigh, c->rpl, nrpl);
+            tab_bs[tq] = (uint8_t)bs;
+            /* derive_max_filter_length_luma (:374-397) */
+            {
+                const int size_p = tb_size[tp], size_q = tb_size[tq];
+                const int off_p = (py >> f->min_cb_log2) * f->min_cb_width + (px >> f->min_cb_log2);
+                if (size_p <= 4 || size_q <= 4) {
+                    len_p = len_q = 1;
+                } else {
+                    len_p = len_q = 3;
+                    if (size_p >= 32) len_p = 7;
+                    if (size_q >= 32) len_q = 7;
+                }
+                if (has_sb) len_q = orc_min(5, len_q);
+                if (BS_U8(f->msf)[off_p] || BS_U8(f->iaf)[off_p]) len_p = orc_min(5, len_p);
+            }
+            tab_p[tq] = (uint8_t)len_p;
+            tab_q[tq] = (uint8_t)len_q;
+        }
+    }
+    if (sb_cu) {
+        /* vvc_deblock_subblock_bs_vertical / _horizontal (:399-475): internal edges every 8 samples from the coding block origin */
+        for (int i = 8 - ((a0 - (dir ? cb_x : cb_y)) % 8); i < across; i += 8)
+            for (int j = 0; j < along; j += 4) {
+                const int qx = dir ? x0 + i : x0 + j, qy = dir ? y0 + j : y0 + i;
+                const int px = dir ? qx - 1 : qx, py = dir ? qy : qy - 1;
+                const orc_mvfield *neigh = &c->mvf[(py >> 2) * mpw + (px >> 2)], *curr = &c->mvf[(qy >> 2) * mpw + (qx >> 2)];
+                const int t = BS_TU(f, qx, qy);
+                const int len = (i == 4 || i == across - 4) ? 1 : (i == 8 || i == across - 8) ? 2 : 3;
+                tab_bs[t] = (uint8_t)bs_boundary_strength(curr, neigh, c->rpl, c->rpl);
+                tab_p[t] = tab_q[t] = (uint8_t)len;
+            }
+    }
+}
+
+static void bs_chroma_tu(const bs_ctx *c, int dir, int x0, int y0, int width, int height)
+{
+    const orc_bs_frame *f = c->f;
+    const int mpw = f->min_pu_width;
+    const int a0 = dir ? x0 : y0, along = dir ? height : width;
+    const int ctb_mask = (1 << f->ctb_log2) - 1;
+    int boundary = a0 > 0 && !(a0 & ((8 << (dir ? f->hs : f->vs)) - 1));
+    if (boundary && ((!f->lfase && (dir ? c->left_slice : c->upper_slice) && !(a0 & ctb_mask)) ||
+                     (!f->lfate && (dir ? c->left_tile : c->upper_tile) && !(a0 & ctb_mask))))
+        boundary = 0;
+    if (!boundary)
+        return;
+    for (int i = 0; i < along; i += 2) {
+        const int qx = dir ? x0 : x0 + i, qy = dir ? y0 + i : y0;
+        const int px = dir ? qx - 1 : qx, py = dir ? qy : qy - 1;
+        const orc_mvfield *neigh = &c->mvf[(py >> 2) * mpw + (px >> 2)], *curr = &c->mvf[(qy >> 2) * mpw + (qx >> 2)];
+        const int tq = BS_TU(f, qx, qy), tp = BS_TU(f, px, py);
+        const int pcmf = BS_U8(f->pcmf[1])[tp] && BS_U8(f->pcmf[1])[tq];
+        for (int k = 1; k <= 2; k++) {
+            const int cbf = BS_U8(f->tu_coded_flag[k])[tp] | BS_U8(f->tu_coded_flag[k])[tq] | BS_U8(f->tu_joint_cbcr)[tp] | BS_U8(f->tu_joint_cbcr)[tq];
+            int bs = 0;
+            if (pcmf)
+                bs = 0;
+            else if (curr->pred_flag == 0 || neigh->pred_flag == 0 || curr->ciip_flag || neigh->ciip_flag)
+                bs = 2;
+            else if (cbf)
+                bs = 1;
+            BS_U8(f->bs[dir][k])[tq] = (uint8_t)bs;
+        }
+    }
+}
+
+ORC_API void orc_deblock_bs_pass(const orc_bs_frame *f)
+{
+    const int ctb_size = 1 << f->ctb_log2;
+    const int ctb_height = (f->height + ctb_size - 1) >> f->ctb_log2;
+    const int16_t *slice = (const int16_t *)(uintptr_t)f->slice_idx;
+    const int16_t *col_bd = (const int16_t *)(uintptr_t)f->ctb_to_col_bd, *row_bd = (const int16_t *)(uintptr_t)f->ctb_to_row_bd;
+    const size_t n_tu = (size_t)f->min_tu_width * (f->height >> 2);
+    for (int dir = 0; dir < 2; dir++) {
+        for (int k = 0; k < (f->n_comp >= 3 ? 3 : 1); k++) memset(BS_U8(f->bs[dir][k]), 0, n_tu);
+        memset(BS_U8(f->max_len_p[dir]), 0, n_tu);
+        memset(BS_U8(f->max_len_q[dir]), 0, n_tu);
+    }
+    for (int ry = 0; ry < ctb_height; ry++)
+        for (int rx = 0; rx < f->ctb_width; rx++) {
+            const int rs = ry * f->ctb_width + rx;
+            bs_ctx c = { f, (const orc_mvfield *)(uintptr_t)f->mvf, BS_I32(f->ref_poc) + slice[rs] * 64, 0, 0, 0, 0, rx, ry };
+            c.left_tile   = rx > 0 && col_bd[rx] != col_bd[rx - 1];
+            c.left_slice  = rx > 0 && slice[rs] != slice[rs - 1];
+            c.upper_tile  = ry > 0 && row_bd[ry] != row_bd[ry - 1];
+            c.upper_slice = ry > 0 && slice[rs] != slice[rs - f->ctb_width];
+            const int x0 = rx << f->ctb_log2, y0 = ry << f->ctb_log2;
+            const int x_end = orc_min(x0 + ctb_size, f->width) >> 2, y_end = orc_min(y0 + ctb_size, f->height) >> 2;
+            for (int dir = 1; dir >= 0; dir--)
+                for (int tree = 0; tree < (f->n_comp >= 3 ? 2 : 1); tree++) {
+                    const int hs = tree ? f->hs : 0, vs = tree ? f->vs : 0;
+                    for (int y = y0 >> 2; y < y_end; y++)
+                        for (int x = x0 >> 2; x < x_end; x++) {
+                            const int off = y * f->min_tu_width + x;
+                            if ((BS_I32(f->tb_pos_x0[tree])[off] >> 2) != x || (BS_I32(f->tb_pos_y0[tree])[off] >> 2) != y)
+                                continue;
+                            const int w = BS_U8(f->tb_width[tree])[off] << hs, h = BS_U8(f->tb_height[tree])[off] << vs;
+                            if (tree) bs_chroma_tu(&c, dir, x << 2, y << 2, w, h);
+                            else      bs_luma_tu(&c, dir, x << 2, y << 2, w, h);
+                        }
+                }
+        }
+}

@@ -1,0 +1,168 @@
+"""Synthetic but self-consistent decoder side tables for the boundary-strength stage (vvc355_deblock_bs_pass): a random
+partition of every CTB into coding blocks and transform units (luma tree, and an independent chroma tree in dual-tree CTBs),
+motion fields, coded flags, slices and tiles — laid out as VVCFrameContext.tab holds them (vvcdec.h:122-187).  Used by the GPU
+parity test, the CPU oracle tests and bench.py."""
+import ctypes
+
+import numpy as np
+
+from ffvvc_amd import abi
+
+
+def _split(rng, x, y, w, h, pw, ph, min_size, out):
+    """Random quad / binary partition of the rectangle into leaves that lie inside the picture and are at most 64 wide."""
+    if x >= pw or y >= ph:
+        return
+    inside = x + w <= pw and y + h <= ph
+    if not inside:
+        min_size = 8                    # picture sizes are multiples of 8: forced splits may go down to that
+    must = not inside or w > 64 or h > 64
+    can_q = w == h and w >= 2 * min_size
+    if must or (max(w, h) > min_size and rng.random() < (0.75 if max(w, h) > 16 else 0.35)):
+        kind = int(rng.integers(0, 3))
+        if must and not inside:
+            kind = 0 if can_q else (1 if x + w > pw else 2)
+        if kind == 0 and can_q:
+            for dy in (0, h // 2):
+                for dx in (0, w // 2):
+                    _split(rng, x + dx, y + dy, w // 2, h // 2, pw, ph, min_size, out)
+            return
+        if (kind == 1 or h <= min_size) and w > min_size:
+            _split(rng, x, y, w // 2, h, pw, ph, min_size, out)
+            _split(rng, x + w // 2, y, w // 2, h, pw, ph, min_size, out)
+            return
+        if h > min_size:
+            _split(rng, x, y, w, h // 2, pw, ph, min_size, out)
+            _split(rng, x, y + h // 2, w, h // 2, pw, ph, min_size, out)
+            return
+    out.append((x, y, w, h))
+
+
+class BsTables:
+    """Host arrays + the descriptor; `frame(ptr_of)` fills an abi.BsFrame with addresses from `ptr_of(array)`."""
+
+    IN = ("mvf", "ref_poc", "slice_idx", "col_bd", "row_bd", "cbf0", "cbf1", "cbf2", "joint", "pcm0", "pcm1",
+          "tbx0", "tbx1", "tby0", "tby1", "tbw0", "tbw1", "tbh0", "tbh1", "cbx", "cby", "cbw", "cbh", "msf", "iaf")
+    OUT = ("bs00", "bs01", "bs02", "bs10", "bs11", "bs12", "p0", "p1", "q0", "q1")
+
+    def __init__(self, rng, width, height, ctb_log2=7, n_slices=1, tiles=False, lfase=1, lfate=1, inter_frac=0.8):
+        assert width % 8 == 0 and height % 8 == 0
+        self.width, self.height, self.ctb_log2 = width, height, ctb_log2
+        ctb = 1 << ctb_log2
+        self.cw, self.ch = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
+        self.tw, self.th = width // 4, height // 4
+        self.lfase, self.lfate = lfase, lfate
+        n = self.tw * self.th
+        u8 = lambda: np.zeros((self.th, self.tw), np.uint8)        # noqa: E731
+        i32 = lambda: np.zeros((self.th, self.tw), np.int32)       # noqa: E731
+        self.mvf = np.zeros((self.th, self.tw), dtype=np.dtype(abi.MvField))
+        self.cbf0, self.cbf1, self.cbf2, self.joint, self.pcm0, self.pcm1 = u8(), u8(), u8(), u8(), u8(), u8()
+        self.tbx0, self.tbx1, self.tby0, self.tby1 = i32(), i32(), i32(), i32()
+        self.tbw0, self.tbw1, self.tbh0, self.tbh1 = u8(), u8(), u8(), u8()
+        self.cbx, self.cby, self.cbw, self.cbh, self.msf, self.iaf = i32(), i32(), u8(), u8(), u8(), u8()
+        # slices: raster runs of CTBs; tiles: two columns x two rows
+        nctb = self.cw * self.ch
+        cuts = np.sort(rng.integers(1, max(2, nctb), size=n_slices - 1)) if n_slices > 1 else []
+        self.slice_idx = np.searchsorted(cuts, np.arange(nctb), side="right").astype(np.int16)
+        if tiles and self.cw > 2 and self.ch > 1:
+            cx, cy = int(rng.integers(1, self.cw)), int(rng.integers(1, self.ch))
+            self.col_bd = np.array([0 if x < cx else cx for x in range(self.cw)] + [self.cw], np.int16)
+            self.row_bd = np.array([0 if y < cy else cy for y in range(self.ch)] + [self.ch], np.int16)
+        else:
+            self.col_bd = np.array([0] * self.cw + [self.cw], np.int16)
+            self.row_bd = np.array([0] * self.ch + [self.ch], np.int16)
+        # POC lists with repeats, so that "same reference picture" holds across lists and slices now and then
+        self.ref_poc = rng.choice(np.array([0, 4, 8], np.int32), size=(max(1, n_slices), 2, 32)).astype(np.int32)
+        gmv = rng.integers(-40, 41, size=(2, 2))
+        for ry in range(self.ch):
+            for rx in range(self.cw):
+                self._ctb(rng, rx * ctb, ry * ctb, ctb, gmv, inter_frac)
+        assert np.all(self.tbw0 > 0) and np.all(self.tbw1 > 0) and np.all(self.cbw > 0), "partition does not cover the picture"
+        assert np.all(self.tbx0 + self.tbw0 <= width) and np.all(self.tby0 + self.tbh0 <= height)
+        assert np.all(self.tbx1 + 2 * self.tbw1.astype(int) <= width) and np.all(self.tby1 + 2 * self.tbh1.astype(int) <= height)
+        for name in self.OUT:
+            setattr(self, name, np.full((self.th, self.tw), 0xEE, np.uint8))
+
+    def _fill_tu(self, tree, x, y, w, h, shift):
+        s = np.s_[y // 4:(y + h) // 4, x // 4:(x + w) // 4]
+        (self.tbx1 if tree else self.tbx0)[s], (self.tby1 if tree else self.tby0)[s] = x, y
+        (self.tbw1 if tree else self.tbw0)[s], (self.tbh1 if tree else self.tbh0)[s] = w >> shift, h >> shift
+        return s
+
+    def _ctb(self, rng, x0, y0, ctb, gmv, inter_frac):
+        dual = rng.random() < 0.25
+        leaves = []
+        _split(rng, x0, y0, ctb, ctb, self.width, self.height, 8, leaves)
+        for (x, y, w, h) in leaves:
+            s = np.s_[y // 4:(y + h) // 4, x // 4:(x + w) // 4]
+            self.cbx[s], self.cby[s], self.cbw[s], self.cbh[s] = x, y, w, h
+            inter = not dual and rng.random() < inter_frac
+            m = self.mvf[s]
+            if inter:
+                pf = int(rng.choice([1, 2, 3, 3]))
+                m["pred_flag"] = pf
+                m["ciip_flag"] = int(rng.random() < 0.05)
+                m["ref_idx"] = rng.integers(0, 3, size=2)
+                base = gmv + rng.integers(-9, 10, size=(2, 2))
+                m["mv"] = base
+                if rng.random() < 0.3:
+                    # sub-block coding block (affine or sub-block merge): own motion per 8x8
+                    (self.iaf if rng.random() < 0.5 else self.msf)[s] = 1
+                    for by in range(0, h, 8):
+                        for bx in range(0, w, 8):
+                            self.mvf[(y + by) // 4:(y + by + 8) // 4, (x + bx) // 4:(x + bx + 8) // 4]["mv"] = base + rng.integers(-7, 8, size=(2, 2))
+            # luma transform units: the coding block, or 2 / 4 strips of it
+            parts = [(x, y, w, h)]
+            r = rng.random()
+            if r < 0.2 and w >= 16:
+                k = int(rng.choice([2, 4]))
+                parts = [(x + i * w // k, y, w // k, h) for i in range(k)]
+            elif r < 0.4 and h >= 16:
+                k = int(rng.choice([2, 4]))
+                parts = [(x, y + i * h // k, w, h // k) for i in range(k)]
+            for (tx, ty, tw, th) in parts:
+                ts = self._fill_tu(0, tx, ty, tw, th, 0)
+                self.cbf0[ts] = int(rng.random() < 0.4)
+                self.pcm0[ts] = int(rng.random() < 0.2)
+            if not dual:
+                ts = self._fill_tu(1, x, y, w, h, 1)
+                self.cbf1[ts], self.cbf2[ts] = int(rng.random() < 0.3), int(rng.random() < 0.3)
+                self.joint[ts], self.pcm1[ts] = int(rng.random() < 0.1), int(rng.random() < 0.2)
+        if dual:
+            cl = []
+            _split(rng, x0, y0, ctb, ctb, self.width, self.height, 16, cl)
+            for (x, y, w, h) in cl:
+                ts = self._fill_tu(1, x, y, w, h, 1)
+                self.cbf1[ts], self.cbf2[ts] = int(rng.random() < 0.3), int(rng.random() < 0.3)
+                self.joint[ts], self.pcm1[ts] = int(rng.random() < 0.1), int(rng.random() < 0.2)
+
+    def frame(self, ptr_of):
+        f = abi.BsFrame()
+        f.mvf, f.ref_poc, f.slice_idx = ptr_of("mvf"), ptr_of("ref_poc"), ptr_of("slice_idx")
+        f.ctb_to_col_bd, f.ctb_to_row_bd = ptr_of("col_bd"), ptr_of("row_bd")
+        for c in range(3):
+            f.tu_coded_flag[c] = ptr_of(f"cbf{c}")
+        f.tu_joint_cbcr = ptr_of("joint")
+        for t in range(2):
+            f.pcmf[t], f.tb_pos_x0[t], f.tb_pos_y0[t] = ptr_of(f"pcm{t}"), ptr_of(f"tbx{t}"), ptr_of(f"tby{t}")
+            f.tb_width[t], f.tb_height[t] = ptr_of(f"tbw{t}"), ptr_of(f"tbh{t}")
+        f.cb_pos_x, f.cb_pos_y, f.cb_width, f.cb_height = ptr_of("cbx"), ptr_of("cby"), ptr_of("cbw"), ptr_of("cbh")
+        f.msf, f.iaf = ptr_of("msf"), ptr_of("iaf")
+        for d in range(2):
+            for c in range(3):
+                f.bs[d][c] = ptr_of(f"bs{d}{c}")
+            f.max_len_p[d], f.max_len_q[d] = ptr_of(f"p{d}"), ptr_of(f"q{d}")
+        f.width, f.height = self.width, self.height
+        f.min_tu_width = f.min_pu_width = f.min_cb_width = self.tw
+        f.ctb_width = self.cw
+        f.ctb_log2, f.min_cb_log2, f.hs, f.vs, f.n_comp = self.ctb_log2, 2, 1, 1, 3
+        f.lfase, f.lfate = self.lfase, self.lfate
+        return f
+
+
+def run_oracle(orc, t):
+    orc.orc_deblock_bs_pass.argtypes = [ctypes.POINTER(abi.BsFrame)]
+    orc.orc_deblock_bs_pass.restype = None
+    f = t.frame(lambda name: getattr(t, name).ctypes.data)
+    orc.orc_deblock_bs_pass(ctypes.byref(f))
+    return {name: getattr(t, name).copy() for name in t.OUT}

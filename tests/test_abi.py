@@ -40,4 +40,5 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.DequantJob) == 32
     assert ctypes.sizeof(abi.BipredJob) == 96 and ctypes.sizeof(abi.BipredResult) == 32
     assert ctypes.sizeof(abi.AffineJob) == 88
+    assert ctypes.sizeof(abi.MvField) == 24 and ctypes.sizeof(abi.BsFrame) == 312
     assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136

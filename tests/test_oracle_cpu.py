@@ -329,3 +329,32 @@ def test_alf_frame_pass_matches_slot_chain_on_one_ctb(orc, bd):
                               P(cc, 7), 60)
         for c in range(3):
             assert np.array_equal(got[c], want[c]), f"component {c}"
+
+
+def test_deblock_bs_oracle_rules(orc):
+    """orc_deblock_bs_pass (vvc_deblock_bs restated, vvc_filter.c:308-783) on synthetic side tables: entries appear only on
+    transform-unit or sub-block edges; intra on either side gives 2; an all-intra picture has no strength-1 chroma entry without
+    coded flags; slice edges that must not be filtered stay 0."""
+    import bs_cases
+    rng = np.random.default_rng(0xB5)
+    t = bs_cases.BsTables(rng, 264, 136, 6, n_slices=3, tiles=False, lfase=0, lfate=1)
+    out = bs_cases.run_oracle(orc, t)
+    ys, xs = np.mgrid[0:t.th, 0:t.tw]
+    # vertical edges: a non-zero luma entry sits on a transform-unit origin column or inside a sub-block coding block
+    on_tu = t.tbx0 == xs * 4
+    cbo = (t.tby0 // 4, t.tbx0 // 4)
+    sb = (t.msf[cbo] | t.iaf[cbo]).astype(bool)
+    assert not np.any((out["bs10"] > 0) & ~on_tu & ~sb)
+    assert not np.any((out["p1"] > 0) & ~on_tu & ~sb)
+    # intra on either side of a transform-unit edge: 2, unless both sides are pcm
+    left_pf = np.roll(t.mvf["pred_flag"], 1, axis=1)
+    edge = on_tu & (xs > 0)
+    ctb_cols = (xs * 4) % 64 == 0
+    slice_of = t.slice_idx.reshape(t.ch, t.cw)[ys * 4 // 64, xs * 4 // 64]
+    slice_left = np.roll(slice_of, 1, axis=1)
+    off = ctb_cols & (slice_of != slice_left)
+    both_pcm = (t.pcm0 & np.roll(t.pcm0, 1, axis=1)).astype(bool)
+    sel = edge & ~off & ~both_pcm & ((t.mvf["pred_flag"] == 0) | (left_pf == 0))
+    assert np.all(out["bs10"][sel] == 2) and sel.sum() > 50
+    assert np.all(out["bs10"][edge & off] == 0) and (edge & off).sum() > 0
+    assert np.all(out["bs10"][:, 0] == 0) and np.all(out["bs00"][0, :] == 0)
