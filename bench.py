@@ -335,24 +335,49 @@ def build_chain(lib, torch, fr):
 
     frame_bytes = sum(w * h for (w, h) in fr.dims) * isz
 
+    # ---------------------------------------------------------------- boundary strengths: the decoder's side tables -> bS / max filter lengths
+    bs_dev = None
+    if not DEBLOCK_JOBS:
+        # a self-consistent random partition (coding blocks 8..64, transform-unit strips, 80 % inter with sub-block blocks, coded
+        # flags) of a quarter-width picture, repeated four times across: about 70 % of the 4-sample segments on the 8-sample
+        # grid end up filtered
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import bs_cases
+        assert fr.width % (4 * CTB) == 0
+        reps = 4
+        bt = bs_cases.BsTables(np.random.default_rng(0x5EED0B5), fr.width // reps, fr.height, 7, split=(0.95, 0.45), cbf_p=0.4)
+        bs_dev = {}
+        for name in bt.IN + bt.OUT:
+            a = getattr(bt, name)
+            if name in ("slice_idx",):
+                a = np.zeros(fr.n_ctus, np.int16)
+            elif name in ("col_bd",):
+                a = np.zeros(fr.ncx + 1, np.int16)
+            elif a.ndim == 2 and a.shape == (bt.th, bt.tw):
+                a = np.tile(a, (1, reps))
+                if name in ("tbx0", "tbx1", "cbx"):
+                    a = a + (np.arange(reps * bt.tw) // bt.tw * (fr.width // reps)).astype(a.dtype)[None, :]
+            a = np.ascontiguousarray(a)
+            bs_dev[name] = fr.upload(a.view(np.uint8) if a.dtype.kind == "V" else a)
+        bt.width, bt.tw, bt.cw = fr.width, bt.tw * reps, fr.ncx
+        bsf = bt.frame(lambda name: ptr(bs_dev[name]))
+        d_bsf = fr.upload(np.frombuffer(bytes(bsf), np.uint8))
+        fr.keep.append(bsf)
+        n_units = (fr.width // 4) * (fr.height // 4)
+        chain.append(Stage("deblock_bs", "deblock_bs_kernel", lambda st: lib.vvc355_deblock_bs_pass(st, ptr(d_bsf), ctypes.addressof(bsf)),
+                           n_units * (24 + 2 * 10 + 6 + 10)))       # MvField + both trees' TU tables + flags read, 10 table bytes written
+
     def deblock_tables(vertical):
-        """The side tables one pass of the stage driver reads (vvc355_deblock_frame): transform edges every 8 luma samples
-        (every 16 for chroma = its 8-sample grid), boundary strength 1 or 2 on 60 % of the 4-sample segments, filter lengths
-        1..3, QP 22..42, per-CTU beta / tc offsets, LADF on."""
+        """The side tables one pass of the stage driver reads (vvc355_deblock_frame): boundary strengths and luma filter lengths
+        as the deblock_bs stage leaves them, the chroma transform sizes of the same partition, QP 22..42, per-CTU beta / tc
+        offsets, LADF on."""
         tw, th = fr.width // 4, fr.height // 4
         f = abi.DeblockFrame()
-        pos = (np.arange(tw) * 4)[None, :] if vertical else (np.arange(th) * 4)[:, None]
         tabs = []
         for c in range(3):
-            on_edge = (pos % (16 if c else 8) == 0) & (pos > 0)
-            bs = np.where(on_edge & (rng.random((th, tw)) < 0.6), rng.integers(1, 3, size=(th, tw)), 0).astype(np.uint8)
-            tabs.append(fr.upload(bs))
-            f.plane[c], f.stride[c], f.bs[c] = ptr(rec[c]), fr.pitch(rec[c]), ptr(tabs[-1])
-        for key in ("max_len_p", "max_len_q"):
-            tabs.append(fr.upload(rng.choice([1, 2, 3], size=(th, tw)).astype(np.uint8)))
-            setattr(f, key, ptr(tabs[-1]))
-        tabs.append(fr.upload(rng.choice([4, 8, 16], size=(th, tw)).astype(np.uint8)))
-        f.tb_size_c = ptr(tabs[-1])
+            f.plane[c], f.stride[c], f.bs[c] = ptr(rec[c]), fr.pitch(rec[c]), ptr(bs_dev[f"bs{vertical}{c}"])
+        f.max_len_p, f.max_len_q = ptr(bs_dev[f"p{vertical}"]), ptr(bs_dev[f"q{vertical}"])
+        f.tb_size_c = ptr(bs_dev["tbw1" if vertical else "tbh1"])
         tabs.append(fr.upload(rng.integers(22, 43, size=(fr.height // 8, fr.width // 8)).astype(np.int8)))
         f.qp_y = ptr(tabs[-1])
         for k in range(2):
@@ -578,6 +603,14 @@ def cpu_baseline(root, fr, budget_s):
             row.append(j)
         bp_jobs.append(row)
 
+    # boundary strengths of one CTB's worth of side tables (same partition statistics as build_chain)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import bs_cases
+    bs_t = bs_cases.BsTables(np.random.default_rng(0x5EED0B5), CTB, CTB, 7, split=(0.95, 0.45), cbf_p=0.4)
+    bs_f = bs_t.frame(lambda name: getattr(bs_t, name).ctypes.data)
+    orc.orc_deblock_bs_pass.argtypes = [ctypes.POINTER(abi.BsFrame)]
+    orc.orc_deblock_bs_pass.restype = None
+
     def one_ctu():
         # regular bi-prediction with DMVR + BDOF: 64 luma 16x16 sub-blocks, then their 2 x 64 chroma 8x8 blocks
         for b in range(64):
@@ -592,6 +625,7 @@ def cpu_baseline(root, fr, budget_s):
                 orc.orc_itx(0, 0, lg, lg, A(r), min(s, 12), min(s, 12), 15, bd)
                 orc.orc_add_residual(bd, A(dst), A(r), s, s, CTB * isz)
         orc.orc_lmcs_filter(bd, A(dst), CTB * isz, CTB, CTB, A(lut))
+        orc.orc_deblock_bs_pass(ctypes.byref(bs_f))
         # deblock: 15 x 16 vertical and horizontal luma edge segments pairs + chroma
         for d in (1, 0):
             for e in range(15 * 16 + 2 * 7 * 8):

@@ -963,10 +963,15 @@ __device__ __forceinline__ vvc355_mvfield ld_mvf(const vvc355_mvfield *p)
 // One lane per 4x4 luma unit; both edge directions (dir 1 = vertical edges: neighbour on the left, dir 0 = horizontal edges:
 // neighbour above).  Gather form of vvc_deblock_bs (vvc_filter.c:756-783): the unit asks which rule of the transform unit
 // covering it wrote its entry in the reference's scatter loops.
+//
+// The kernel is a chain of table look-ups, so it is organised by memory round trips, not by rules: phase 1 issues every load whose
+// address depends on the lane's position only (its own and the two neighbouring MvFields, the transform-unit tables of both
+// trees, the coded / pcm flags of the unit and of its two neighbours, slice and tile numbers), unconditionally and with clamped
+// indices; phase 2 the few loads addressed by the transform unit's origin (its coding block); then the rules run on registers.
 __global__ __launch_bounds__(256) void deblock_bs_kernel(const vvc355_bs_frame *__restrict__ fp)
 {
-    const VVC355_CONST vvc355_bs_frame &F = *(const VVC355_CONST vvc355_bs_frame *)fp;
-    const int mtw = F.min_tu_width, mpw = F.min_pu_width;
+    const vvc355_bs_frame F = load_uniform(fp);
+    const int mtw = F.min_tu_width, mpw = F.min_pu_width, mcl = F.min_cb_log2, mcw = F.min_cb_width;
     const int ux = blockIdx.x * 64 + (threadIdx.x & 63), uy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int x = ux * 4, y = uy * 4;
     if (x >= F.width || y >= F.height)
@@ -976,77 +981,97 @@ __global__ __launch_bounds__(256) void deblock_bs_kernel(const vvc355_bs_frame *
     const vvc355_mvfield *mvf = (const vvc355_mvfield *)F.mvf;
     const int16_t *slice = (const int16_t *)F.slice_idx;
     const int ctb = (y >> ctb_log2) * F.ctb_width + (x >> ctb_log2);
-    const int my_slice = gld<int16_t>(slice + ctb);
-    const vvc355_mvfield curr = ld_mvf(mvf + uy * mpw + ux);
 
+    // ---- phase 1
+    const int has_n[2] = { uy > 0, ux > 0 };                                     // [dir]: a P side exists
+    const int offn[2] = { has_n[0] ? off - mtw : off, has_n[1] ? off - 1 : off };
+    const vvc355_mvfield curr = ld_mvf(mvf + uy * mpw + ux);
+    const vvc355_mvfield neigh[2] = { ld_mvf(mvf + (uy - has_n[0]) * mpw + ux), ld_mvf(mvf + uy * mpw + ux - has_n[1]) };
+    int t0[2][2];                                                                // [tree][dir]: the transform unit's origin across the edge
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        t0[t][1] = gld<int>((const int *)F.tb_pos_x0[t] + off);
+        t0[t][0] = gld<int>((const int *)F.tb_pos_y0[t] + off);
+    }
+    const int size_q[2] = { gld<uint8_t>((const uint8_t *)F.tb_height[0] + off), gld<uint8_t>((const uint8_t *)F.tb_width[0] + off) };
+    const int size_p[2] = { gld<uint8_t>((const uint8_t *)F.tb_height[0] + offn[0]), gld<uint8_t>((const uint8_t *)F.tb_width[0] + offn[1]) };
+    const uint8_t *flag_tab[6] = { (const uint8_t *)F.pcmf[0], (const uint8_t *)F.tu_coded_flag[0], (const uint8_t *)F.pcmf[1],
+                                   (const uint8_t *)F.tu_coded_flag[1], (const uint8_t *)F.tu_coded_flag[2], (const uint8_t *)F.tu_joint_cbcr };
+    int fq[6], fn[2][6];                                                         // pcm0, cbf0, pcm1, cbf1, cbf2, joint: here / on the P side
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        fq[k] = gld<uint8_t>(flag_tab[k] + off);
+        fn[0][k] = gld<uint8_t>(flag_tab[k] + offn[0]);
+        fn[1][k] = gld<uint8_t>(flag_tab[k] + offn[1]);
+    }
+    int sb_p[2];                                                                 // the P side lies in a sub-block coding block
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const int px = d ? x - has_n[1] : x, py = d ? y : y - has_n[0];
+        const int cbp = (py >> mcl) * mcw + (px >> mcl);
+        sb_p[d] = gld<uint8_t>((const uint8_t *)F.msf + cbp) | gld<uint8_t>((const uint8_t *)F.iaf + cbp);
+    }
+    const int my_slice = gld<int16_t>(slice + ctb);
+    int n_slice[2], tile_edge[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const int a = d ? x : y;
+        const bool on_ctb_edge = a > 0 && !(a & ctb_mask);
+        n_slice[d] = gld<int16_t>(slice + (on_ctb_edge ? (d ? ctb - 1 : ctb - F.ctb_width) : ctb));
+        const int16_t *bd = (const int16_t *)(d ? F.ctb_to_col_bd : F.ctb_to_row_bd);
+        const int r = max(a >> ctb_log2, 1);
+        tile_edge[d] = on_ctb_edge && gld<int16_t>(bd + r) != gld<int16_t>(bd + r - 1);
+    }
+    // ---- phase 2: the luma transform unit's origin and the coding block there
+    const int tx0 = t0[0][1], ty0 = t0[0][0];
+    const bool is_intra = gld<uint8_t>((const uint8_t *)(mvf + (ty0 >> 2) * mpw + (tx0 >> 2)) + 20) == 0;
+    const int cbo = (ty0 >> mcl) * mcw + (tx0 >> mcl);
+    const int cb0[2] = { gld<int>((const int *)F.cb_pos_y + cbo), gld<int>((const int *)F.cb_pos_x + cbo) };
+    const int cb_size[2] = { gld<uint8_t>((const uint8_t *)F.cb_height + cbo), gld<uint8_t>((const uint8_t *)F.cb_width + cbo) };
+    const bool sb_cu = !is_intra && (gld<uint8_t>((const uint8_t *)F.msf + cbo) | gld<uint8_t>((const uint8_t *)F.iaf + cbo));
+
+    // ---- phase 3: the rules
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
         const int a = dir ? x : y;                              // coordinate across the edge
-        // ---- may the CTB edge this unit sits on be filtered at all? (:498-507, :583-591)
-        bool ctb_edge_off = false;
-        int n_slice = my_slice;
-        if (a > 0 && !(a & ctb_mask)) {
-            const int nctb = dir ? ctb - 1 : ctb - F.ctb_width;
-            n_slice = gld<int16_t>(slice + nctb);
-            const int16_t *bd = (const int16_t *)(dir ? F.ctb_to_col_bd : F.ctb_to_row_bd);
-            const int r = a >> ctb_log2;
-            const bool tile_edge = gld<int16_t>(bd + r) != gld<int16_t>(bd + r - 1);
-            ctb_edge_off = (!F.lfase && n_slice != my_slice) || (!F.lfate && tile_edge);
-        }
-        const int noff = dir ? off - 1 : off - mtw;             // the P-side unit
-        const vvc355_mvfield *np = mvf + (dir ? uy * mpw + ux - 1 : (uy - 1) * mpw + ux);
+        // a CTB edge that must not be filtered (:498-507, :583-591)
+        const bool ctb_edge_off = (!F.lfase && n_slice[dir] != my_slice) || (!F.lfate && tile_edge[dir]);
+        const bool strong = curr.pred_flag == 0 || neigh[dir].pred_flag == 0 || curr.ciip_flag || neigh[dir].ciip_flag;
         // ---- luma tree
         int bs = 0, len_p = 0, len_q = 0;
-        {
-            const int tx0 = gld<int>((const int *)F.tb_pos_x0[0] + off), ty0 = gld<int>((const int *)F.tb_pos_y0[0] + off);
-            const int t0 = dir ? tx0 : ty0;                      // the transform unit's origin across the edge
-            const uint8_t *tb_size = (const uint8_t *)(dir ? F.tb_width[0] : F.tb_height[0]);
-            const int tsize = gld<uint8_t>(tb_size + off);
-            const bool is_intra = gld<uint8_t>((const uint8_t *)(mvf + (ty0 >> 2) * mpw + (tx0 >> 2)) + 20) == 0;
-            const int cbo = (ty0 >> F.min_cb_log2) * F.min_cb_width + (tx0 >> F.min_cb_log2);
-            const int cb0 = gld<int>((const int *)(dir ? F.cb_pos_x : F.cb_pos_y) + cbo);
-            const int cb_size = gld<uint8_t>((const uint8_t *)(dir ? F.cb_width : F.cb_height) + cbo);
-            const bool sb_cu = !is_intra && (gld<uint8_t>((const uint8_t *)F.msf + cbo) || gld<uint8_t>((const uint8_t *)F.iaf + cbo));
-            const bool has_sb = sb_cu && cb_size > 8;
-            if (a == t0) {
-                if (a > 0 && !ctb_edge_off) {
-                    // transform-block edge (:509-545)
-                    const vvc355_mvfield neigh = ld_mvf(np);
-                    const uint8_t *cbf = (const uint8_t *)F.tu_coded_flag[0], *pcm = (const uint8_t *)F.pcmf[0];
-                    const int off_c = cb0 - t0;
-                    if (gld<uint8_t>(pcm + noff) && gld<uint8_t>(pcm + off))
-                        bs = 0;
-                    else if (curr.pred_flag == 0 || neigh.pred_flag == 0 || curr.ciip_flag || neigh.ciip_flag)
-                        bs = 2;
-                    else if (gld<uint8_t>(cbf + off) || gld<uint8_t>(cbf + noff))
-                        bs = 1;
-                    else if (off_c && ((off_c & 7) || !has_sb))
-                        bs = 0;
-                    else
-                        bs = bs_motion(curr, neigh, (const int *)F.ref_poc + my_slice * 64, (const int *)F.ref_poc + n_slice * 64);
-                    // derive_max_filter_length_luma (:374-397)
-                    const int size_p = gld<uint8_t>(tb_size + noff);
-                    if (size_p <= 4 || tsize <= 4) {
-                        len_p = len_q = 1;
-                    } else {
-                        len_p = size_p >= 32 ? 7 : 3;
-                        len_q = tsize >= 32 ? 7 : 3;
-                    }
-                    if (has_sb)
-                        len_q = min(5, len_q);
-                    const int px = dir ? x - 1 : x, py = dir ? y : y - 1;
-                    const int cbp = (py >> F.min_cb_log2) * F.min_cb_width + (px >> F.min_cb_log2);
-                    if (gld<uint8_t>((const uint8_t *)F.msf + cbp) || gld<uint8_t>((const uint8_t *)F.iaf + cbp))
-                        len_p = min(5, len_p);
+        const bool has_sb = sb_cu && cb_size[dir] > 8;
+        if (a == t0[0][dir]) {
+            if (a > 0 && !ctb_edge_off) {
+                // transform-block edge (:509-545)
+                const int off_c = cb0[dir] - a;
+                if (fn[dir][0] && fq[0])
+                    bs = 0;
+                else if (strong)
+                    bs = 2;
+                else if (fq[1] || fn[dir][1])
+                    bs = 1;
+                else if (off_c && ((off_c & 7) || !has_sb))
+                    bs = 0;
+                else
+                    bs = bs_motion(curr, neigh[dir], (const int *)F.ref_poc + my_slice * 64, (const int *)F.ref_poc + n_slice[dir] * 64);
+                // derive_max_filter_length_luma (:374-397)
+                if (size_p[dir] <= 4 || size_q[dir] <= 4) {
+                    len_p = len_q = 1;
+                } else {
+                    len_p = size_p[dir] >= 32 ? 7 : 3;
+                    len_q = size_q[dir] >= 32 ? 7 : 3;
                 }
-            } else if (sb_cu && !((a - cb0) & 7)) {
-                // sub-block edge inside the transform unit (:399-475), both sides in the current slice
-                const vvc355_mvfield neigh = ld_mvf(np);
-                const int *rpl = (const int *)F.ref_poc + my_slice * 64;
-                bs = bs_motion(curr, neigh, rpl, rpl);
-                const int i = a - t0;
-                len_p = len_q = (i == 4 || i == tsize - 4) ? 1 : (i == 8 || i == tsize - 8) ? 2 : 3;
+                if (has_sb)
+                    len_q = min(5, len_q);
+                if (sb_p[dir])
+                    len_p = min(5, len_p);
             }
+        } else if (sb_cu && !((a - cb0[dir]) & 7)) {
+            // sub-block edge inside the transform unit (:399-475), both sides in the current slice
+            const int *rpl = (const int *)F.ref_poc + my_slice * 64;
+            bs = bs_motion(curr, neigh[dir], rpl, rpl);
+            const int i = a - t0[0][dir], tsize = size_q[dir];
+            len_p = len_q = (i == 4 || i == tsize - 4) ? 1 : (i == 8 || i == tsize - 8) ? 2 : 3;
         }
         gst<uint8_t>((uint8_t *)F.bs[dir][0] + off, (uint8_t)bs);
         gst<uint8_t>((uint8_t *)F.max_len_p[dir] + off, (uint8_t)len_p);
@@ -1054,25 +1079,15 @@ __global__ __launch_bounds__(256) void deblock_bs_kernel(const vvc355_bs_frame *
         if (F.n_comp < 3)
             continue;
         // ---- chroma tree (:642-754): transform-block edges on the 8-sample chroma grid only
-        int bs_c[2] = { 0, 0 };
-        {
-            const int t0 = gld<int>((const int *)(dir ? F.tb_pos_x0[1] : F.tb_pos_y0[1]) + off);
-            const int grid = (8 << (dir ? F.hs : F.vs)) - 1;
-            if (a == t0 && a > 0 && !(a & grid) && !ctb_edge_off) {
-                const vvc355_mvfield neigh = ld_mvf(np);
-                const uint8_t *pcm = (const uint8_t *)F.pcmf[1], *jc = (const uint8_t *)F.tu_joint_cbcr;
-                const bool pcmf = gld<uint8_t>(pcm + noff) && gld<uint8_t>(pcm + off);
-                const bool strong = curr.pred_flag == 0 || neigh.pred_flag == 0 || curr.ciip_flag || neigh.ciip_flag;
-                const int joint = gld<uint8_t>(jc + noff) | gld<uint8_t>(jc + off);
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint8_t *cbf = (const uint8_t *)F.tu_coded_flag[c + 1];
-                    bs_c[c] = pcmf ? 0 : strong ? 2 : (gld<uint8_t>(cbf + noff) | gld<uint8_t>(cbf + off) | joint) ? 1 : 0;
-                }
-            }
+        int bs_cb = 0, bs_cr = 0;
+        const int grid = (8 << (dir ? F.hs : F.vs)) - 1;
+        if (a == t0[1][dir] && a > 0 && !(a & grid) && !ctb_edge_off && !(fn[dir][2] && fq[2])) {
+            const int joint = fn[dir][5] | fq[5];
+            bs_cb = strong ? 2 : (fn[dir][3] | fq[3] | joint) ? 1 : 0;
+            bs_cr = strong ? 2 : (fn[dir][4] | fq[4] | joint) ? 1 : 0;
         }
-        gst<uint8_t>((uint8_t *)F.bs[dir][1] + off, (uint8_t)bs_c[0]);
-        gst<uint8_t>((uint8_t *)F.bs[dir][2] + off, (uint8_t)bs_c[1]);
+        gst<uint8_t>((uint8_t *)F.bs[dir][1] + off, (uint8_t)bs_cb);
+        gst<uint8_t>((uint8_t *)F.bs[dir][2] + off, (uint8_t)bs_cr);
     }
 }
 

@@ -9,7 +9,7 @@ import numpy as np
 from ffvvc_amd import abi
 
 
-def _split(rng, x, y, w, h, pw, ph, min_size, out):
+def _split(rng, x, y, w, h, pw, ph, min_size, out, p_big=0.75, p_small=0.35):
     """Random quad / binary partition of the rectangle into leaves that lie inside the picture and are at most 64 wide."""
     if x >= pw or y >= ph:
         return
@@ -18,22 +18,22 @@ def _split(rng, x, y, w, h, pw, ph, min_size, out):
         min_size = 8                    # picture sizes are multiples of 8: forced splits may go down to that
     must = not inside or w > 64 or h > 64
     can_q = w == h and w >= 2 * min_size
-    if must or (max(w, h) > min_size and rng.random() < (0.75 if max(w, h) > 16 else 0.35)):
+    if must or (max(w, h) > min_size and rng.random() < (p_big if max(w, h) > 16 else p_small)):
         kind = int(rng.integers(0, 3))
         if must and not inside:
             kind = 0 if can_q else (1 if x + w > pw else 2)
         if kind == 0 and can_q:
             for dy in (0, h // 2):
                 for dx in (0, w // 2):
-                    _split(rng, x + dx, y + dy, w // 2, h // 2, pw, ph, min_size, out)
+                    _split(rng, x + dx, y + dy, w // 2, h // 2, pw, ph, min_size, out, p_big, p_small)
             return
         if (kind == 1 or h <= min_size) and w > min_size:
-            _split(rng, x, y, w // 2, h, pw, ph, min_size, out)
-            _split(rng, x + w // 2, y, w // 2, h, pw, ph, min_size, out)
+            _split(rng, x, y, w // 2, h, pw, ph, min_size, out, p_big, p_small)
+            _split(rng, x + w // 2, y, w // 2, h, pw, ph, min_size, out, p_big, p_small)
             return
         if h > min_size:
-            _split(rng, x, y, w, h // 2, pw, ph, min_size, out)
-            _split(rng, x, y + h // 2, w, h // 2, pw, ph, min_size, out)
+            _split(rng, x, y, w, h // 2, pw, ph, min_size, out, p_big, p_small)
+            _split(rng, x, y + h // 2, w, h // 2, pw, ph, min_size, out, p_big, p_small)
             return
     out.append((x, y, w, h))
 
@@ -45,7 +45,7 @@ class BsTables:
           "tbx0", "tbx1", "tby0", "tby1", "tbw0", "tbw1", "tbh0", "tbh1", "cbx", "cby", "cbw", "cbh", "msf", "iaf")
     OUT = ("bs00", "bs01", "bs02", "bs10", "bs11", "bs12", "p0", "p1", "q0", "q1")
 
-    def __init__(self, rng, width, height, ctb_log2=7, n_slices=1, tiles=False, lfase=1, lfate=1, inter_frac=0.8):
+    def __init__(self, rng, width, height, ctb_log2=7, n_slices=1, tiles=False, lfase=1, lfate=1, inter_frac=0.8, split=(0.75, 0.35), cbf_p=0.4):
         assert width % 8 == 0 and height % 8 == 0
         self.width, self.height, self.ctb_log2 = width, height, ctb_log2
         ctb = 1 << ctb_log2
@@ -74,6 +74,7 @@ class BsTables:
         # POC lists with repeats, so that "same reference picture" holds across lists and slices now and then
         self.ref_poc = rng.choice(np.array([0, 4, 8], np.int32), size=(max(1, n_slices), 2, 32)).astype(np.int32)
         gmv = rng.integers(-40, 41, size=(2, 2))
+        self.split, self.cbf_p = split, cbf_p
         for ry in range(self.ch):
             for rx in range(self.cw):
                 self._ctb(rng, rx * ctb, ry * ctb, ctb, gmv, inter_frac)
@@ -92,7 +93,7 @@ class BsTables:
     def _ctb(self, rng, x0, y0, ctb, gmv, inter_frac):
         dual = rng.random() < 0.25
         leaves = []
-        _split(rng, x0, y0, ctb, ctb, self.width, self.height, 8, leaves)
+        _split(rng, x0, y0, ctb, ctb, self.width, self.height, 8, leaves, *self.split)
         for (x, y, w, h) in leaves:
             s = np.s_[y // 4:(y + h) // 4, x // 4:(x + w) // 4]
             self.cbx[s], self.cby[s], self.cbw[s], self.cbh[s] = x, y, w, h
@@ -122,7 +123,7 @@ class BsTables:
                 parts = [(x, y + i * h // k, w, h // k) for i in range(k)]
             for (tx, ty, tw, th) in parts:
                 ts = self._fill_tu(0, tx, ty, tw, th, 0)
-                self.cbf0[ts] = int(rng.random() < 0.4)
+                self.cbf0[ts] = int(rng.random() < self.cbf_p)
                 self.pcm0[ts] = int(rng.random() < 0.2)
             if not dual:
                 ts = self._fill_tu(1, x, y, w, h, 1)
@@ -130,7 +131,7 @@ class BsTables:
                 self.joint[ts], self.pcm1[ts] = int(rng.random() < 0.1), int(rng.random() < 0.2)
         if dual:
             cl = []
-            _split(rng, x0, y0, ctb, ctb, self.width, self.height, 16, cl)
+            _split(rng, x0, y0, ctb, ctb, self.width, self.height, 16, cl, *self.split)
             for (x, y, w, h) in cl:
                 ts = self._fill_tu(1, x, y, w, h, 1)
                 self.cbf1[ts], self.cbf2[ts] = int(rng.random() < 0.3), int(rng.random() < 0.3)

@@ -21,6 +21,7 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "intra_pred": "intra_pred_kernel",
     "dequant_itx_add_residual": "itx_shape_kernel",
     "lmcs_inverse_luma": "lmcs_kernel",
+    "deblock_bs": "deblock_bs_kernel",
     "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
     "deblock_horizontal": "deblock_frame_kernel",   # second one
     "sao": "sao_frame_kernel",
