@@ -546,6 +546,16 @@ def recorded_traffic(root, stage_name):
     return json.load(open(path)).get(stage_name, {}).get("hbm_bytes_per_launch")
 
 
+def recorded_valu(root, stage_name):
+    """VALU instruction counts / issue utilisation of the stage's kernel from the committed rocprofv3 --pmc SQ_* passes
+    (profiles/mc_valu.json), or None."""
+    path = os.path.join(root, "profiles", "mc_valu.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get(stage_name)
+    return None if d is None else {k: d[k] for k in ("valu_insts_per_wave", "valu_issue_utilisation", "by_tool_valu_per_wave")}
+
+
 def cpu_baseline(root, fr, budget_s):
     """The CPU oracle (oracle/liborc.so, a scalar C restatement: kind "port") timed on ONE host core over a bounded sample
     of the same per-CTU work: one inter CTU's worth of every stage, repeated; reported in frames/s of the same chain."""
@@ -780,6 +790,7 @@ def main():
                 "ms_per_launch": stage_ms[dom.name],
                 "algorithmic_bytes_per_launch": dom.algorithmic_bytes,
                 "traffic": recorded_traffic(ROOT, dom.name),
+                "valu": recorded_valu(ROOT, dom.name),    # recorded SQ counters: the dominant kernel is bound by VALU issue, not by HBM
             },
             "stages": stages,
         }
