@@ -45,13 +45,13 @@ class BsTables:
           "tbx0", "tbx1", "tby0", "tby1", "tbw0", "tbw1", "tbh0", "tbh1", "cbx", "cby", "cbw", "cbh", "msf", "iaf")
     OUT = ("bs00", "bs01", "bs02", "bs10", "bs11", "bs12", "p0", "p1", "q0", "q1")
 
-    def __init__(self, rng, width, height, ctb_log2=7, n_slices=1, tiles=False, lfase=1, lfate=1, inter_frac=0.8, split=(0.75, 0.35), cbf_p=0.4):
+    def __init__(self, rng, width, height, ctb_log2=7, n_slices=1, tiles=False, lfase=1, lfate=1, inter_frac=0.8, split=(0.75, 0.35), cbf_p=0.4, hs=1, vs=1):
         assert width % 8 == 0 and height % 8 == 0
         self.width, self.height, self.ctb_log2 = width, height, ctb_log2
         ctb = 1 << ctb_log2
         self.cw, self.ch = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
         self.tw, self.th = width // 4, height // 4
-        self.lfase, self.lfate = lfase, lfate
+        self.lfase, self.lfate, self.hs, self.vs = lfase, lfate, hs, vs
         n = self.tw * self.th
         u8 = lambda: np.zeros((self.th, self.tw), np.uint8)        # noqa: E731
         i32 = lambda: np.zeros((self.th, self.tw), np.int32)       # noqa: E731
@@ -80,14 +80,15 @@ class BsTables:
                 self._ctb(rng, rx * ctb, ry * ctb, ctb, gmv, inter_frac)
         assert np.all(self.tbw0 > 0) and np.all(self.tbw1 > 0) and np.all(self.cbw > 0), "partition does not cover the picture"
         assert np.all(self.tbx0 + self.tbw0 <= width) and np.all(self.tby0 + self.tbh0 <= height)
-        assert np.all(self.tbx1 + 2 * self.tbw1.astype(int) <= width) and np.all(self.tby1 + 2 * self.tbh1.astype(int) <= height)
+        assert np.all(self.tbx1 + (self.tbw1.astype(int) << hs) <= width) and np.all(self.tby1 + (self.tbh1.astype(int) << vs) <= height)
         for name in self.OUT:
             setattr(self, name, np.full((self.th, self.tw), 0xEE, np.uint8))
 
     def _fill_tu(self, tree, x, y, w, h, shift):
         s = np.s_[y // 4:(y + h) // 4, x // 4:(x + w) // 4]
         (self.tbx1 if tree else self.tbx0)[s], (self.tby1 if tree else self.tby0)[s] = x, y
-        (self.tbw1 if tree else self.tbw0)[s], (self.tbh1 if tree else self.tbh0)[s] = w >> shift, h >> shift
+        (self.tbw1 if tree else self.tbw0)[s] = w >> (self.hs if shift else 0)
+        (self.tbh1 if tree else self.tbh0)[s] = h >> (self.vs if shift else 0)
         return s
 
     def _ctb(self, rng, x0, y0, ctb, gmv, inter_frac):
@@ -156,7 +157,7 @@ class BsTables:
         f.width, f.height = self.width, self.height
         f.min_tu_width = f.min_pu_width = f.min_cb_width = self.tw
         f.ctb_width = self.cw
-        f.ctb_log2, f.min_cb_log2, f.hs, f.vs, f.n_comp = self.ctb_log2, 2, 1, 1, 3
+        f.ctb_log2, f.min_cb_log2, f.hs, f.vs, f.n_comp = self.ctb_log2, 2, self.hs, self.vs, 3
         f.lfase, f.lfate = self.lfase, self.lfate
         return f
 

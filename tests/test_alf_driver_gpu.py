@@ -21,17 +21,18 @@ def smooth(rng, shape, bd):
     return np.clip(base + noise, 0, (1 << bd) - 1).astype(np.uint8 if bd == 8 else np.uint16)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd,fmt", [(8, (1, 1)), (10, (1, 1)), (12, (1, 1)), (10, (1, 0)), (10, (0, 0))])
 @pytest.mark.parametrize("mode", ["across", "slices", "tiles", "both"])
-def test_alf_frame_pass(dev, orc, bd, mode):
+def test_alf_frame_pass(dev, orc, bd, fmt, mode):
+    hs, vs = fmt                                          # 4:2:0, 4:2:2, 4:4:4
     orc.orc_alf_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.AlfFrame)]
     orc.orc_alf_frame_pass.restype = None
-    rng = np.random.default_rng(0x5EED0A00 + bd + len(mode))
+    rng = np.random.default_rng(0x5EED0A00 + bd + len(mode) + 16 * hs + 32 * vs)
     w, h, ctb_log2 = 328, 200, 6
     ctb = 1 << ctb_log2
     cw, ch = (w + ctb - 1) // ctb, (h + ctb - 1) // ctb
     n = cw * ch
-    dims = [(w, h), (w // 2, h // 2), (w // 2, h // 2)]
+    dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
     isz = 1 if bd == 8 else 2
     src = [smooth(rng, (d[1], d[0]), bd) for d in dims]
     want = [np.full_like(p, 0x21) for p in src]
@@ -77,7 +78,7 @@ def test_alf_frame_pass(dev, orc, bd, mode):
         f.alf, f.slices = alf_p, slices_p
         f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = tp
         f.width, f.height, f.ctb_width, f.ctb_height = w, h, cw, ch
-        f.ctb_log2, f.hs, f.vs, f.n_comp = ctb_log2, 1, 1, 3
+        f.ctb_log2, f.hs, f.vs, f.n_comp = ctb_log2, hs, vs, 3
         f.lfase = int(mode in ("across", "tiles"))
         f.lfate = int(mode in ("across", "slices"))
 

@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
     dict(width=416, height=240, ctb_log2=7, n_slices=4, tiles=True, lfase=1, lfate=0),
     dict(width=416, height=240, ctb_log2=7, n_slices=4, tiles=True, lfase=0, lfate=1),
     dict(width=264, height=136, ctb_log2=5, n_slices=5, tiles=True, lfase=0, lfate=0),
+    dict(width=328, height=200, ctb_log2=6, n_slices=3, tiles=True, lfase=0, lfate=0, hs=1, vs=0),
+    dict(width=328, height=200, ctb_log2=6, n_slices=2, tiles=False, lfase=1, lfate=1, hs=0, vs=0),
     dict(width=1920, height=1080 - 1080 % 8, ctb_log2=7, n_slices=2, tiles=False, lfase=1, lfate=1, inter_frac=0.95),
 ])
 def test_deblock_bs_pass(dev, orc, cfg):

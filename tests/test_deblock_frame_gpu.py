@@ -13,7 +13,7 @@ from ffvvc_amd import abi, batch
 pytestmark = pytest.mark.gpu
 
 
-def side_tables(rng, w, h, vertical):
+def side_tables(rng, w, h, vertical, shift=1):
     """A random but self-consistent transform-block partition and the tables one pass reads (all per 4x4 luma unit)."""
     tw, th = w // 4, h // 4
     tsize = np.zeros((th, tw), np.uint8)                 # tb_width (vertical pass) / tb_height (horizontal) in luma samples
@@ -31,7 +31,7 @@ def side_tables(rng, w, h, vertical):
             if pos % t:
                 continue                                  # not a transform edge
             bs[0, y, x] = rng.choice([0, 1, 2], p=[0.3, 0.35, 0.35])
-            if pos % 16 == 0:                             # chroma edges live on the 8-sample chroma grid
+            if pos % (8 << shift) == 0:                   # chroma edges live on the 8-sample chroma grid
                 bs[1, y, x] = rng.choice([0, 1, 2], p=[0.3, 0.35, 0.35])
                 bs[2, y, x] = rng.choice([0, 1, 2], p=[0.3, 0.35, 0.35])
     len_p, len_q = np.zeros((th, tw), np.uint8), np.zeros((th, tw), np.uint8)
@@ -48,14 +48,15 @@ def side_tables(rng, w, h, vertical):
     return tsize, bs, len_p, len_q
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
-def test_deblock_frame_pass(dev, orc, bd):
+@pytest.mark.parametrize("bd,fmt", [(8, (1, 1)), (10, (1, 1)), (12, (1, 1)), (10, (1, 0)), (10, (0, 0)), (8, (0, 0))])
+def test_deblock_frame_pass(dev, orc, bd, fmt):
+    hs, vs = fmt                                          # 4:2:0, 4:2:2, 4:4:4
     orc.orc_deblock_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.DeblockFrame)]
     orc.orc_deblock_frame_pass.restype = None
-    rng = np.random.default_rng(0x5EED0340 + bd)
+    rng = np.random.default_rng(0x5EED0340 + bd + 16 * hs + 32 * vs)
     w, h, ctb_log2 = 256, 160, 6
     isz = 1 if bd == 8 else 2
-    dims = [(w, h), (w // 2, h // 2), (w // 2, h // 2)]
+    dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
     planes = []
     for (pw, ph) in dims:
         base = bc.smooth_picture(rng, ph, pw, bd, scale=32).astype(np.int64)
@@ -71,8 +72,9 @@ def test_deblock_frame_pass(dev, orc, bd):
     dbp = rng.integers(-7, 8, size=(ctb_w * ctb_h, 6)).astype(np.int8)
     changed = 0
     for vertical in (1, 0):                               # all vertical edges first, then all horizontal (vvc_thread.c:159-167)
-        tsize, bs, len_p, len_q = side_tables(rng, w, h, vertical)
-        tb_c = np.maximum(tsize // 2, 2).astype(np.uint8)
+        shift = hs if vertical else vs
+        tsize, bs, len_p, len_q = side_tables(rng, w, h, vertical, shift)
+        tb_c = np.maximum(tsize >> shift, 2).astype(np.uint8)
         host_tabs = [bs[0], bs[1], bs[2], len_p, len_q, tb_c, qp_y, qp_c[0], qp_c[1], dbp]
         dev_tabs = [batch.DeviceBuffer.from_host(np.ascontiguousarray(t)) for t in host_tabs]
 
@@ -82,7 +84,7 @@ def test_deblock_frame_pass(dev, orc, bd):
             f.max_len_p, f.max_len_q, f.tb_size_c, f.qp_y = tabs[3], tabs[4], tabs[5], tabs[6]
             f.qp_c[0], f.qp_c[1], f.db_params = tabs[7], tabs[8], tabs[9]
             f.width, f.height, f.min_tu_width, f.min_cb_width, f.ctb_width = w, h, tw, w // 8, ctb_w
-            f.min_cb_log2, f.ctb_log2, f.hs, f.vs, f.n_comp, f.vertical = 3, ctb_log2, 1, 1, 3, vertical
+            f.min_cb_log2, f.ctb_log2, f.hs, f.vs, f.n_comp, f.vertical = 3, ctb_log2, hs, vs, 3, vertical
             f.qp_bd_offset = 6 * (bd - 8)
             f.ladf_enabled, f.num_ladf_intervals, f.ladf_lowest_qp_offset = 1, 4, -3
             for k, v in enumerate((2, -1, 4, 0)):

@@ -74,19 +74,20 @@ def test_sao_ctb_batch(dev, orc, bd, dims):
     assert len(bad) == 0, f"{len(bad)} samples differ, first at {bad[0].tolist()}"
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd,fmt", [(8, (1, 1)), (10, (1, 1)), (12, (1, 1)), (10, (1, 0)), (10, (0, 0))])
 @pytest.mark.parametrize("mode", ["across", "slices", "tiles", "both"])
-def test_sao_frame_pass(dev, orc, bd, mode):
+def test_sao_frame_pass(dev, orc, bd, fmt, mode):
     """The SAO stage driver (vvc355_sao_frame_pass: per-CTB flags and parameters derived on the device from the decoder's
     tables) vs the oracle's restatement of ff_vvc_sao_filter on the same tables; 4:2:0, partial CTBs at the right / bottom."""
     import ctypes
     orc.orc_sao_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.SaoFrame)]
     orc.orc_sao_frame_pass.restype = None
-    rng = np.random.default_rng(0x5EED0850 + bd + len(mode))
+    hs, vs = fmt                                          # 4:2:0, 4:2:2, 4:4:4
+    rng = np.random.default_rng(0x5EED0850 + bd + len(mode) + 16 * hs + 32 * vs)
     w, h, ctb_log2 = 328, 200, 6
     ctb = 1 << ctb_log2
     cw, ch = (w + ctb - 1) // ctb, (h + ctb - 1) // ctb
-    dims = [(w, h), (w // 2, h // 2), (w // 2, h // 2)]
+    dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
     isz = 1 if bd == 8 else 2
     src = [rand_pixels(rng, (d[1], d[0]), bd) for d in dims]
     if bd > 8:
@@ -114,7 +115,7 @@ def test_sao_frame_pass(dev, orc, bd, mode):
             f.dst[c], f.src[c], f.dst_stride[c], f.src_stride[c] = dst_ptrs[c], src_ptrs[c], dstrides[c], sstrides[c]
         f.sao, f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = tp
         f.width, f.height, f.ctb_width, f.ctb_height = w, h, cw, ch
-        f.ctb_log2, f.hs, f.vs, f.n_comp = ctb_log2, 1, 1, 3
+        f.ctb_log2, f.hs, f.vs, f.n_comp = ctb_log2, hs, vs, 3
         f.lfase = int(mode in ("across", "tiles"))
         f.no_tile_filter = int(mode in ("tiles", "both"))
 
