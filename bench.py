@@ -794,7 +794,7 @@ def main():
             },
             "stages": stages,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # a reported baseline, timed once: rank 0 of the single-GPU run
             out["cpu_baseline"] = cpu_baseline(ROOT, frame, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -492,9 +492,11 @@ __device__ static const int16_t kAlfZeroSet[25 * 12] = { 0 };
 // ff_vvc_alf_filter (vvc_filter.c:1254-1318) per CTB as a descriptor builder: one lane per CTB writes its luma job, two chroma
 // jobs and two CC-ALF jobs.  edges[] (:1264-1278) become ext_* = 0 (replicate) / 3 (read the neighbour in place).
 template <int BD>
-__global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ fp, int n_ctbs, vvc355_alf_job *luma, vvc355_alf_job *chroma,
+__global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int n_ctbs, vvc355_alf_job *luma, vvc355_alf_job *chroma,
                                  vvc355_alf_job *cc, int16_t *clips)
 {
+    const vvc355_alf_frame F = load_uniform(frame);       // scalar loads, once: the fields are read dozens of times
+    const vvc355_alf_frame *fp = &F;
     const int rs = blockIdx.x * blockDim.x + threadIdx.x;
     if (rs >= n_ctbs)
         return;
