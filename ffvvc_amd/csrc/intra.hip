@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
         return;
     uint16_t (*arr)[kEdgeLen] = arr_all[sub];
     int *scratch = scratch_all[sub];
-    const vvc355_intra_job j = jobs[ji];
+    // a wave (or the workgroup) per job: the descriptor comes through the scalar cache; two jobs per wave: per-lane loads
+    const vvc355_intra_job j = NT >= 64 ? load_uniform(jobs + __builtin_amdgcn_readfirstlane(ji)) : jobs[ji];
     const int stride = j.stride / (int)sizeof(typename Px<BD>::type);      // pixels; int keeps the row offsets full-rate 24-bit multiplies
     const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x % NT;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
@@ -300,14 +301,16 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
 #define GETP(x, y) ld_px<BD>(src, (x) + __mul24(stride, (y)))
     for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
     for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)GETP(i, ref_line);
+    // the corner samples -1 .. ref_line (at most four) go out with the edge loads, on the last lanes of the group
+    if (j.cand_up_left && tid >= NT + ref_line) {
+        const int i = tid - NT;
+        left[i] = (uint16_t)GETP(ref_line, i);
+        top[i] = (uint16_t)GETP(i, ref_line);
+    }
     group_sync<NT>();
-    if (tid == 0) {
-        for (int i = -1; i >= ref_line; i--) {
-            if (j.cand_up_left) { left[i] = (uint16_t)GETP(ref_line, i); top[i] = (uint16_t)GETP(i, ref_line); }
-            else if (la) left[i] = top[i] = left[0];
-            else if (ta) left[i] = top[i] = top[0];
-            else left[i] = top[i] = 1 << (BD - 1);
-        }
+    if (!j.cand_up_left && tid < -ref_line) {
+        const int i = -1 - tid;
+        left[i] = top[i] = la ? left[0] : ta ? top[0] : (uint16_t)(1 << (BD - 1));
     }
     group_sync<NT>();
     {
