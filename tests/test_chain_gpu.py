@@ -27,7 +27,7 @@ class Side:
         return addr
 
 
-@pytest.mark.parametrize("bd,fmt,ctb_log2", [(10, (1, 1), 6), (8, (1, 1), 7), (10, (0, 0), 5), (12, (1, 0), 6)])
+@pytest.mark.parametrize("bd,fmt,ctb_log2", [(10, (1, 1), 6), (8, (1, 1), 7), (10, (0, 0), 5), (12, (1, 0), 6), (10, (0, 0), 7)])
 def test_loop_filter_chain(dev, orc, bd, fmt, ctb_log2):
     hs, vs = fmt
     for name, ty in (("orc_deblock_frame_pass", abi.DeblockFrame), ("orc_sao_frame_pass", abi.SaoFrame), ("orc_alf_frame_pass", abi.AlfFrame)):
