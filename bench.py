@@ -793,6 +793,19 @@ def main():
             },
             "stages": stages,
         }
+        # what a plain device-to-device copy reaches on this box (report the practical peak beside the vendor figure)
+        n_copy = 1 << 28
+        a_buf = torch.empty(n_copy, dtype=torch.uint8, device="cuda")
+        b_buf = torch.empty_like(a_buf)
+        b_buf.copy_(a_buf)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            b_buf.copy_(a_buf)
+        c1.record()
+        torch.cuda.synchronize()
+        out["roofline"]["measured_copy_GBps"] = 2 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9      # read + write
+        del a_buf, b_buf
         if not args.no_cpu_baseline and world == 1:       # a reported baseline, timed once: rank 0 of the single-GPU run
             out["cpu_baseline"] = cpu_baseline(ROOT, frame, args.cpu_seconds)
         print(json.dumps(out), flush=True)
