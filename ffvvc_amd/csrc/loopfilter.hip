@@ -268,20 +268,27 @@ __device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job, int bx)
     }
     uint32_t out[4][4];
     if (type == 1) {
-        int band[4];
+        // band filter (h2656_sao_template.c:24) two samples per operation: band = sample >> (bd - 5); (band - band_position) & 31
+        // below 4 selects offset_val[1..4], anything else adds nothing — the same five-entry byte look-up as the edge categories
+        uint32_t lo_a = 0, hi_a = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) band[k] = (k + job.band_position) & 31;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t o = (uint16_t)job.offset_val[k + 1];
+            lo_a |= (o & 0xff) << (8 * k);
+            hi_a |= (o >> 8) << (8 * k);
+        }
+        const pk16 pos = pk_splat(job.band_position), four = pk_splat(4), zero = pk_splat(0), top = pk_splat((1 << BD) - 1);
+        const uint32_t sh = (BD - 5) * 0x10001u;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int s = (v[r + 1][j >> 1] >> ((j & 1) * 16)) & 0xffff;
-                const int b = (s >> (BD - 5)) & 31;
-                int off = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (b == band[k]) off = job.offset_val[k + 1];
-                const uint32_t pv = (uint32_t)clip_px<BD>(s + off);
-                out[r][j >> 1] = (j & 1) ? out[r][j >> 1] | (pv << 16) : pv;
+            for (int i = 0; i < 4; i++) {
+                uint32_t band;
+                asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(band) : "v"(sh), "v"(v[r + 1][i]));
+                const uint32_t idx = un(pk_min(pk(un(pk(band) - pos) & 0x001f001fu), four));
+                const uint32_t off = __builtin_amdgcn_perm(0u, lo_a, idx | 0x0c000c00u) | __builtin_amdgcn_perm(0u, hi_a, (idx << 8) | 0x000c000cu);
+                const pk16 t = __builtin_elementwise_add_sat(pk(v[r + 1][i]), pk(off));
+                out[r][i] = un(pk_min(pk_max(t, zero), top));
             }
     } else {
         // category -> offset as two byte look-ups (v_perm_b32): low bytes and high bytes of offset_val[kSaoCat[0..4]]
