@@ -363,6 +363,9 @@ def build_chain(lib, torch, fr):
         d_bsf = fr.upload(np.frombuffer(bytes(bsf), np.uint8))
         fr.keep.append(bsf)
         n_units = (fr.width // 4) * (fr.height // 4)
+        # the deblocking passes read these tables: fill them once here, so that they are valid even when --only drops the stage
+        lib.vvc355_deblock_bs_pass(None, ptr(d_bsf), ctypes.addressof(bsf))
+        lib.vvc355_stream_sync(None)
         chain.append(Stage("deblock_bs", "deblock_bs_kernel", lambda st: lib.vvc355_deblock_bs_pass(st, ptr(d_bsf), ctypes.addressof(bsf)),
                            n_units * (24 + 2 * 10 + 6 + 10)))       # MvField + both trees' TU tables + flags read, 10 table bytes written
 
