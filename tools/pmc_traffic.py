@@ -30,6 +30,8 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
 
 
 def per_stage(directory, counter, n_passes):
+    """Mean counter value per dispatch of every kernel a stage launches (each kernel runs once per step), summed per stage.
+    Means per dispatch, not totals / steps: bench.py launches the bS kernel once more while it builds the chain."""
     path = glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
@@ -38,7 +40,10 @@ def per_stage(directory, counter, n_passes):
         sel = [r for r in rows if pat in r["Kernel_Name"]]
         if pat == "deblock_frame_kernel":
             sel = sel[0::2] if stage == "deblock_vertical" else sel[1::2]
-        out[stage] = sum(float(r["Counter_Value"]) for r in sel) / n_passes
+        by_kernel = {}
+        for r in sel:
+            by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+        out[stage] = sum(sum(v) / len(v) for v in by_kernel.values())
     return out
 
 
