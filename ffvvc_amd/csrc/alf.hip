@@ -314,12 +314,13 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
 
 // alf.filter[CHROMA] (:137): one 6-tap set per rectangle; rectangle up to 128x128 (4:4:4), usually 64x64.
 template <int BD>
-__global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *__restrict__ jobs)
+__global__ __launch_bounds__(256) void alf_chroma_kernel(const vvc355_alf_job *__restrict__ jobs, int log2_strips)
 {
+    // 1 << log2_strips workgroups per job, kStripH rows each (the launcher knows the tallest rectangle, or assumes 128 rows)
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
     const int wg = xcd_chunked(blockIdx.x, gridDim.x);
-    const vvc355_alf_job job = load_uniform(jobs + (wg >> 2));
-    const int y_base = (wg & 3) * kStripH;
+    const vvc355_alf_job job = load_uniform(jobs + (wg >> log2_strips));
+    const int y_base = (wg & ((1 << log2_strips) - 1)) * kStripH;
     if (y_base >= job.h)
         return;
     const int rows = min(kStripH, job.h - y_base);
@@ -597,10 +598,11 @@ static void launch_luma(int bd, int mode, const vvc355_alf_job *jobs, int n, hip
     HIP_CHECK(hipGetLastError());
 }
 
-static void launch_chroma(int bd, const vvc355_alf_job *jobs, int n, hipStream_t st)
+static void launch_chroma(int bd, const vvc355_alf_job *jobs, int n, hipStream_t st, int max_h = 128)
 {
     if (n <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_chroma_kernel<BD>), dim3(n * 4), dim3(256), 0, st, jobs));
+    const int log2_strips = max_h <= kStripH ? 0 : max_h <= 2 * kStripH ? 1 : 2;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_chroma_kernel<BD>), dim3(n << log2_strips), dim3(256), 0, st, jobs, log2_strips));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -662,7 +664,7 @@ void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_d
     HIP_CHECK(hipGetLastError());
     launch_luma(bd, 1, luma, n, st);
     if (frame_host->n_comp >= 3) {
-        launch_chroma(bd, chroma, 2 * n, st);
+        launch_chroma(bd, chroma, 2 * n, st, (1 << frame_host->ctb_log2) >> frame_host->vs);
         launch_cc(bd, cc, 2 * n, st);
     }
 }

@@ -219,13 +219,13 @@ __device__ __forceinline__ void sao_edge8(const uint32_t (&c)[4], const uint32_t
 // samples.  A workgroup covers 128 columns x 64 rows (narrower rectangles: fewer lanes across, more rows).  Only rows / lanes that
 // touch the rectangle's outer ring where a border / restore flag is set take the per-sample path of sao_restore_px.
 template <int BD>
-__device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job, int bx)
+__device__ __forceinline__ void sao_vec_body(const vvc355_sao_job &job, int bx, int tid)
 {
     using px_t = typename Px<BD>::type;
     const int w = job.w, h = job.h, type = job.type;
     const int lxl = w > 64 ? 4 : w > 32 ? 3 : w > 16 ? 2 : w > 8 ? 1 : 0;        // log2 of the lanes across
-    const int x0 = (threadIdx.x & ((1 << lxl) - 1)) * 8;
-    const int y0 = (bx * (256 >> lxl) + (threadIdx.x >> lxl)) * 4;
+    const int x0 = (tid & ((1 << lxl) - 1)) * 8;
+    const int y0 = (bx * (256 >> lxl) + (tid >> lxl)) * 4;
     if (y0 >= h || x0 >= w)
         return;
     const px_t *src = (const px_t *)job.src;
@@ -350,18 +350,21 @@ template <int BD>
 __global__ __launch_bounds__(256) void sao_vec_kernel(const vvc355_sao_job *__restrict__ jobs)
 {
     const vvc355_sao_job job = load_uniform(jobs + blockIdx.y);
-    sao_vec_body<BD>(job, blockIdx.x);
+    sao_vec_body<BD>(job, blockIdx.x, threadIdx.x);
 }
 
 // a[c] for c in 0..2 as selects between the three values: indexing a register copy of a descriptor with a run-time index would
 // put the whole descriptor into scratch memory
 template <typename T> __device__ __forceinline__ T sel3(int c, const T (&a)[3]) { return c == 0 ? a[0] : c == 1 ? a[1] : a[2]; }
 
-// SAO stage driver (ff_vvc_sao_filter, vvc_filter.c:154-300): blockIdx.y = CTB * n_comp + component.  The job the vector body
+// SAO stage driver (ff_vvc_sao_filter, vvc_filter.c:154-300): blockIdx.y = CTB, blockIdx.x = tile of the CTB: tiles_l luma tiles
+// (a tile = what one workgroup of the vector body covers), then the chroma tiles — or, when a chroma CTB needs only half a
+// workgroup (4:2:0), ONE tile whose first two waves take Cb and last two Cr.  (Workgroups and waves that find nothing to do are
+// not free: launching them costs about 3 ns per workgroup, which was a quarter of this kernel's time.)  The job the vector body
 // works on is derived here, on the scalar unit, from the per-CTB tables: picture-border flags (:172-175), unfilterable slice /
 // tile edges (:177-215), type / band position / edge class / offsets of the component.  CTBs without SAO are copied.
 template <int BD>
-__global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *__restrict__ fp, int xg)
+__global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *__restrict__ fp, int xg, int tiles_l, int tiles_c, int packed)
 {
     using px_t = typename Px<BD>::type;
     const vvc355_sao_frame F = load_uniform(fp);
@@ -369,8 +372,11 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
     // neighbouring CTB, which then sits in the same L2.  (Measured: L2 fetch traffic 177 -> 103 MB per 8K frame, 0.087 -> 0.082 ms;
     // one contiguous eighth of the picture per XCD was slower, the XCDs then stream from eight distant DRAM regions.)
     const int lin = xcd_grouped(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, xg);
-    const int by = lin / (int)gridDim.x, bx = lin - by * (int)gridDim.x;
-    const int ctb = by / F.n_comp, c = by - ctb * F.n_comp;
+    const int ctb = lin / (int)gridDim.x, t = lin - ctb * (int)gridDim.x;
+    int c, bx, tid = threadIdx.x, group = 256, ntiles;
+    if (t < tiles_l)  { c = 0; bx = t; ntiles = tiles_l; }
+    else if (packed)  { c = 1 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7); bx = 0; tid = threadIdx.x & 127; group = 128; ntiles = 1; }
+    else              { const int t2 = t - tiles_l; c = 1 + t2 / tiles_c; bx = t2 - (c - 1) * tiles_c; ntiles = tiles_c; }
     const int yc = ctb / F.ctb_width, xc = ctb - yc * F.ctb_width;
     const vvc355_sao_ctb P = load_uniform((const vvc355_sao_ctb *)F.sao + ctb);
     const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
     if (type_idx == 0) {
         // SAO not applied: the samples pass through (16-byte vectors where the row allows, else sample by sample)
         const int w = job.w, h = job.h, wv = w >> 3;
-        for (int i = bx * 256 + threadIdx.x; i < (wv + 1) * h; i += gridDim.x * 256) {
+        for (int i = bx * group + tid; i < (wv + 1) * h; i += ntiles * group) {
             const int y = i / (wv + 1), xv = i - y * (wv + 1);
             const px_t *sp = (const px_t *)((const uint8_t *)job.src + row_off(y, job.src_stride)) + xv * 8;
             px_t *dp = (px_t *)((uint8_t *)job.dst + row_off(y, job.dst_stride)) + xv * 8;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const vvc355_sao_frame *
         if (!eR && !eB) job.diag_edge[2] = (nl && me != slice[ctb + cw + 1]) || rt || bt;
         if (!eL && !eB) job.diag_edge[3] = (nl && me != slice[ctb + cw - 1]) || lt || bt;
     }
-    sao_vec_body<BD>(job, bx);
+    sao_vec_body<BD>(job, bx, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ deblock
@@ -1125,10 +1131,21 @@ void vvc355_deblock_bs_pass(void *stream, const vvc355_bs_frame *frame_dev, cons
 void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_dev, const vvc355_sao_frame *frame_host)
 {
     const vvc355_sao_frame &F = *frame_host;       // host copy: geometry only
-    const int n = F.ctb_width * F.ctb_height * F.n_comp;
+    const int n = F.ctb_width * F.ctb_height;
     if (n <= 0) return;
     const int ctb = 1 << F.ctb_log2;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_frame_kernel<BD>), dim3((ctb + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, frame_dev, 4 * ((ctb + 63) / 64) * F.n_comp));
+    // rows one workgroup of the vector body covers for a rectangle of width w (sao_vec_body: 8 samples x 4 rows per lane)
+    auto rows_per_wg = [](int w) { const int lxl = w > 64 ? 4 : w > 32 ? 3 : w > 16 ? 2 : w > 8 ? 1 : 0; return (256 >> lxl) * 4; };
+    const int tiles_l = (ctb + rows_per_wg(ctb) - 1) / rows_per_wg(ctb);
+    int tiles_c = 0, packed = 0;
+    if (F.n_comp >= 3) {
+        const int wc = ctb >> F.hs, hc = ctb >> F.vs;
+        packed = 2 * hc <= rows_per_wg(wc);
+        tiles_c = (hc + rows_per_wg(wc) - 1) / rows_per_wg(wc);
+    }
+    const int gx = tiles_l + (F.n_comp >= 3 ? (packed ? 1 : 2 * tiles_c) : 0);
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((sao_frame_kernel<BD>), dim3(gx, n), dim3(256), 0, (hipStream_t)stream, frame_dev, 4 * gx,
+                                              tiles_l, tiles_c, packed));
     HIP_CHECK(hipGetLastError());
 }
 
