@@ -789,24 +789,77 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
                                                             int na0, int na1, int ne0, int ne1)
 {
     using px_t = typename Px<BD>::type;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int unit = t >> 1;
-    if (unit >= n_units)
-        return;
     const vvc355_deblock_frame F = load_uniform(fp);
     const int vertical = F.vertical;
-    const int c = unit >= u2 ? 2 : unit >= u1 ? 1 : 0;
+    // ---- phase A, every lane: which segment am I, and is there anything to filter?  Fewer than half of the 4-sample grid
+    // positions carry a boundary strength, so the lanes with work are compacted to the front of the workgroup (one ballot per
+    // wave, wave offsets through LDS) and whole waves leave before the expensive part instead of idling through it.
+    __shared__ uint32_t slot[256];
+    __shared__ int wave_cnt[4];
+    uint32_t desc = 0;
+    bool active = false;
+    {
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        const int unit = t >> 1;
+        if (unit < n_units) {
+            if (unit >= u1) {
+                active = true;                                   // chroma lane: decoded again from its own number below
+                desc = 0x80000000u | threadIdx.x;
+            } else {
+                const int n_edges = ne0, n_along = na0;
+                int ke, ku;
+                if (vertical) { ku = unit / n_edges; ke = unit - ku * n_edges; }
+                else          { ke = unit / n_along; ku = unit - ke * n_along; }
+                const int e = (ke + 1) * 4, u = ku * 8, seg = t & 1;
+                const int x = vertical ? e : u + 4 * seg, y = vertical ? u + 4 * seg : e;
+                if (vertical ? y < F.height : x < F.width) {
+                    const int bs = gld<uint8_t>((const uint8_t *)F.bs[0] + (y >> 2) * F.min_tu_width + (x >> 2));
+                    active = bs != 0;
+                    desc = (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)bs << 28);
+                }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t m = __ballot(active);
+    if (lane == 0)
+        wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int n = wave_cnt[k];
+        if (k < wave) base += n;
+        total += n;
+    }
+    if (active)
+        slot[base + __popcll(m & ((1ull << lane) - 1))] = desc;
+    __syncthreads();
+    if ((int)threadIdx.x >= total)
+        return;
+    const uint32_t mine = slot[threadIdx.x];
+    const bool is_chroma = mine >> 31;
+    // ---- phase B: the segment's parameters and the filter
+    const int t = blockIdx.x * blockDim.x + (is_chroma ? (int)(mine & 255) : 0);
+    const int unit = t >> 1;
+    const int c = !is_chroma ? 0 : unit >= u2 ? 2 : 1;
     const int local = unit - (c == 2 ? u2 : c == 1 ? u1 : 0);
     const int n_along = c ? na1 : na0;
     const int hs = c ? F.hs : 0, vs = c ? F.vs : 0;
     const int grid = c ? (8 << (vertical ? hs : vs)) : 4, step = 8 << (vertical ? vs : hs);
-    // consecutive lanes walk along the rows of the picture: across the edges for the vertical pass, along the edge for the
-    // horizontal one (n_along = units along one edge, n_edges = edges)
     const int n_edges = c ? ne1 : ne0;
-    int ke, ku;
-    if (vertical) { ku = local / n_edges; ke = local - ku * n_edges; }
-    else          { ke = local / n_along; ku = local - ke * n_along; }
-    const int e = (ke + 1) * grid, u = ku * step;                    // edge position across, unit position along (luma units)
+    int e, u;
+    if (is_chroma) {
+        // consecutive units walk along the rows of the picture: across the edges for the vertical pass, along the edge for the
+        // horizontal one (n_along = units along one edge, n_edges = edges)
+        int ke, ku;
+        if (vertical) { ku = local / n_edges; ke = local - ku * n_edges; }
+        else          { ke = local / n_along; ku = local - ke * n_along; }
+        e = (ke + 1) * grid; u = ku * step;                          // edge position across, unit position along (luma units)
+    } else {
+        const int x = mine & 0x3fff, y = (mine >> 14) & 0x3fff;
+        e = vertical ? x : y; u = vertical ? y : x;                  // (u = the segment's own position along the edge)
+    }
     const int ux = vertical ? e : u, uy = vertical ? u : e;
     const int hor_ctu_edge = !vertical && !(e & ((1 << F.ctb_log2) - 1));
     const int ctb = (ux >> F.ctb_log2) + (uy >> F.ctb_log2) * F.ctb_width;
@@ -818,14 +871,8 @@ __global__ __launch_bounds__(256) void deblock_frame_kernel(const vvc355_deblock
     const int xs = vertical ? 1 : pxstride, ys = vertical ? pxstride : 1;
     if (!c) {
         // luma: this lane's one 4-line segment
-        const int seg = t & 1;
-        const int x = vertical ? e : u + 4 * seg, y = vertical ? u + 4 * seg : e;
-        if (vertical ? y >= F.height : x >= F.width)
-            return;
+        const int x = mine & 0x3fff, y = (mine >> 14) & 0x3fff, bs = (mine >> 28) & 3;
         const int tu = (y >> 2) * F.min_tu_width + (x >> 2);
-        const int bs = gld<uint8_t>(bs_tab + tu);
-        if (!bs)
-            return;
         const int xp = x - vertical, yp = y - !vertical;
         uint8_t *pix = plane + row_off(y, stride) + x * (int)sizeof(px_t);
         const int8_t *qy = (const int8_t *)F.qp_y;
@@ -1156,6 +1203,10 @@ void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, 
 
 void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame *frame_dev, const vvc355_deblock_frame *frame_host)
 {
+    if (frame_host->width >= (1 << 14) || frame_host->height >= (1 << 14)) {
+        fprintf(stderr, "vvc_mi355: deblock_frame_pass: picture %dx%d beyond the 14-bit segment coordinates\n", frame_host->width, frame_host->height);
+        abort();
+    }
     // unit counts per component (the host copy of the descriptor is only read for the geometry)
     const vvc355_deblock_frame &F = *frame_host;
     int first[4] = { 0, 0, 0, 0 }, n_along[2] = { 0, 0 }, n_edge[2] = { 0, 0 };
