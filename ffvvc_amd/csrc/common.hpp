@@ -88,6 +88,11 @@ template <int BD> __device__ __forceinline__ void st_px(uint8_t *p, ptrdiff_t i,
     ((VVC355_GLOBAL typename Px<BD>::type *)p)[i] = (typename Px<BD>::type)v;
 }
 
+// Address = wave-uniform base + unsigned 32-bit per-lane byte offset: the form the hardware takes directly (SGPR pair + VGPR
+// offset), so no 64-bit add per access.  Valid for planes below 4 GiB and offsets that are not negative.
+template <typename T> __device__ __forceinline__ T gld_at(const uint8_t *base, uint32_t off) { return gld<T>(base + (size_t)off); }
+template <typename T> __device__ __forceinline__ void gst_at(uint8_t *base, uint32_t off, T v) { gst<T>(base + (size_t)off, v); }
+
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  xcd_chunked() renumbers workgroup b of n so that every
 // XCD works through one contiguous eighth of the job list: neighbouring jobs — neighbouring blocks of the picture, whose
 // reference windows overlap — then meet in the same L2 instead of being fetched from HBM once per XCD.

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void pred_fused_kernel(const vvc355_pred_job *
         else if (mode == 1) p = (v0[i] * w0 + v1[i] * w1 + off) >> shift;
         else if (mode == 2) p = (frac & 3) ? (v0[i] + off) >> shift : v0[i] >> (14 - BD);      // integer position = plain copy
         else                p = ((v0[i] * w0 + off) >> shift) + o0 * (1 << (BD - 8));
-        st_px<BD>(dst + row_off(y, dst_stride), x, clip_px<BD>(p));
+        gst_at<typename Px<BD>::type>(dst, (uint32_t)(__mul24(y, dst_stride) + x * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
     }
 }
 
@@ -266,12 +266,11 @@ __device__ __forceinline__ void fetch_clamped(const uint8_t *plane, int stride, 
                                               uint16_t (&v)[NIT])
 {
     using px_t = typename Px<BD>::type;
-    const int xa = clip3(wx0 + (lane & 31), rc.x0, rc.x1);
-    const uint8_t *col = plane + xa * (int)sizeof(px_t);
+    const int xa = clip3(wx0 + (lane & 31), rc.x0, rc.x1) * (int)sizeof(px_t);
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int ya = clip3(wy0 + (lane >> 5) + 2 * it, rc.y0, rc.y1);
-        v[it] = (uint16_t)gld<px_t>(col + row_off(ya, stride));
+        v[it] = (uint16_t)gld_at<px_t>(plane, (uint32_t)(__mul24(ya, stride) + xa));      // clamped: never negative
     }
 }
 
@@ -299,11 +298,11 @@ __device__ __forceinline__ void fetch_vec4(const uint8_t *plane, int stride, int
 #pragma unroll
     for (int it = 0; it < NV; it++) {
         const int id = lane + 64 * it, r = min(id / 6, nrows - 1), k = id - (id / 6) * 6;    // rows past the window re-read its last row
-        const uint8_t *p = org + row_off(r, stride) + k * 4 * (int)sizeof(px_t);
+        const uint32_t p = (uint32_t)(__mul24(r, stride) + k * 4 * (int)sizeof(px_t));       // org is wave-uniform
         if (BD > 8) {
-            v[it] = gld<uint2>(p);
+            v[it] = gld_at<uint2>(org, p);
         } else {
-            const uint32_t q = gld<uint32_t>(p);
+            const uint32_t q = gld_at<uint32_t>(org, p);
             v[it] = make_uint2(__builtin_amdgcn_perm(0, q, 0x0c010c00u), __builtin_amdgcn_perm(0, q, 0x0c030c02u));
         }
     }
@@ -641,7 +640,8 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
     const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
     const int sh = 15 - BD, off = 1 << (sh - 1);
     const int py = by + q;
-    uint8_t *drow = (uint8_t *)job->dst + row_off(py, job->dst_stride);
+    uint8_t *dst0 = (uint8_t *)job->dst;
+    const uint32_t drow = (uint32_t)__mul24(py, job->dst_stride);
     int out[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -650,9 +650,9 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
         out[k] = clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh);
     }
     if (BD > 8)
-        gst<uint2>(drow + bx * 2, make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16)));
+        gst_at<uint2>(dst0, drow + bx * 2, make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16)));
     else
-        gst<uint32_t>(drow + bx, (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24));
+        gst_at<uint32_t>(dst0, drow + bx, (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24));
 }
 
 // both references at motion mv: windows through clamped coordinates, then the separable interpolation of interp_block
@@ -731,8 +731,15 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
     }
     if (TOOLS && !chroma) {
         int min_sad = 0, searched = 0;
-        if (dmvr)
+        if (dmvr) {
             dmvr_refine<BD>(job, L, lane, mv, bdof, min_sad, searched);
+            // every lane holds the same refined motion: say so, and everything derived from it (positions, fractions, readable
+            // rectangles, filter taps, window base addresses) is scalar work instead of 64 identical lanes of vector work
+#pragma unroll
+            for (int k = 0; k < 4; k++) mv[k] = __builtin_amdgcn_readfirstlane(mv[k]);
+            bdof = __builtin_amdgcn_readfirstlane(bdof);
+            min_sad = __builtin_amdgcn_readfirstlane(min_sad);
+        }
         if (rec && lane == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) gst<int>(&rec->mv[k], mv[k]);
@@ -784,7 +791,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
             if (xu >= w || y >= h)
                 continue;
             const int p = wfu ? ((v0[i] * job->w0 + rnd) >> sh) + job->o0 * (1 << (BD - 8)) : (v0[i] + rnd) >> sh;
-            st_px<BD>(dstu + row_off(y, job->dst_stride), xu, clip_px<BD>(p));
+            gst_at<typename Px<BD>::type>(dstu, (uint32_t)(__mul24(y, job->dst_stride) + xu * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
         }
         return;
     }
@@ -806,7 +813,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
         if (x >= w || y >= h)
             continue;
         const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
-        st_px<BD>(dst + row_off(y, job->dst_stride), x, clip_px<BD>(p));
+        gst_at<typename Px<BD>::type>(dst, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
     }
 }
 
