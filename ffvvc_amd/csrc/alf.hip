@@ -86,20 +86,23 @@ __device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc35
     const int y_min = -min((int)job.ext_t, apron), y_max = h - 1 + min((int)job.ext_b, apron);
     const int nchunk = min(kTileW / 8, (w + 23) >> 3);      // columns -8 .. w+7 only
     const bool aligned = (((uintptr_t)src | (uintptr_t)job.src_stride) & (sizeof(px_t) * 8 - 1)) == 0;
+    // (wave-uniform base, unsigned per-lane offset) addressing: the base sits three rows and eight samples before the rectangle
+    const uint8_t *src_m = src - 3 * job.src_stride - 8 * (int)sizeof(px_t);
 
     for (int i = threadIdx.x; i < (rows + 6) * nchunk; i += blockDim.x) {
         const int r = i / nchunk, k = i - r * nchunk;
         const int y = clip3(y_base + r - 3, y_min, y_max);
         const int c0 = k * 8 - kColOff;
         const px_t *row = (const px_t *)(src + (ptrdiff_t)y * job.src_stride);
+        const uint32_t row_m = (uint32_t)__mul24(y + 3, job.src_stride);       // y >= -3
         uint16_t v[8];
         if (aligned && c0 >= 0 && c0 + 8 <= w) {
             if (BD > 8) {
-                const uint4 q = gld<uint4>(row + c0);
+                const uint4 q = gld_at<uint4>(src_m, row_m + (c0 + 8) * (int)sizeof(px_t));
                 *(uint4 *)&tile[r][k * 8] = q;
                 continue;
             } else {
-                const uint2 q = gld<uint2>(row + c0);
+                const uint2 q = gld_at<uint2>(src_m, row_m + (c0 + 8) * (int)sizeof(px_t));
                 const uint32_t d[2] = { q.x, q.y };
 #pragma unroll
                 for (int j = 0; j < 8; j++)
