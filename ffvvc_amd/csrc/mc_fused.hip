@@ -472,7 +472,7 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
             const uint32_t b = *(const uint32_t *)(L.bil[1][0] + (2 + 2 * r) * kBilP + 2 + 2 * xp);
             acc = __builtin_amdgcn_sad_u16(a, b, 0);
         }
-        min_sad = wave_sum(acc);
+        min_sad = __builtin_amdgcn_readfirstlane(wave_sum(acc));
     }
     min_sad -= min_sad >> 2;
     int min_dx = 2, min_dy = 2;
@@ -512,6 +512,7 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1)
                 key = min(key, (uint32_t)__shfl_xor((int)key, m, 64));
+            key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);     // the same in every lane: the selection below is scalar work
             min_sad = (int)(key >> 5);
             const int kk = key & 31, k = kk ? kk - 1 : 12;
             min_dy = k / 5;
@@ -521,8 +522,9 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
         int dmv0 = (min_dx - 2) * 16, dmv1 = (min_dy - 2) * 16;
         if (min_dx != 0 && min_dx != 4 && min_dy != 0 && min_dy != 4) {
             const int k = min_dy * 5 + min_dx;
-            dmv0 += parametric_mv_refine(L.sad[k - 1], L.sad[k], L.sad[k + 1]);
-            dmv1 += parametric_mv_refine(L.sad[k - 5], L.sad[k], L.sad[k + 5]);
+            const int sc = __builtin_amdgcn_readfirstlane(L.sad[k]);
+            dmv0 += parametric_mv_refine(__builtin_amdgcn_readfirstlane(L.sad[k - 1]), sc, __builtin_amdgcn_readfirstlane(L.sad[k + 1]));
+            dmv1 += parametric_mv_refine(__builtin_amdgcn_readfirstlane(L.sad[k - 5]), sc, __builtin_amdgcn_readfirstlane(L.sad[k + 5]));
         }
         mv[0] = clip3(mv[0] + dmv0, -(1 << 17), (1 << 17) - 1);            // ff_vvc_clip_mv
         mv[1] = clip3(mv[1] + dmv1, -(1 << 17), (1 << 17) - 1);
