@@ -89,6 +89,10 @@ RUNTIME_SIGNATURES = {
     "stream_create":  ("p", ""),
     "stream_destroy": ("v", "p"),
     "stream_sync":    ("v", "p"),
+    "graph_begin":    ("v", "p"),
+    "graph_end":      ("p", "p"),
+    "graph_launch":   ("v", "pp"),
+    "graph_destroy":  ("v", "p"),
     "version":        ("p", ""),
 }
 

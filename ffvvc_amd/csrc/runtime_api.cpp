@@ -29,6 +29,18 @@ void *vvc355_stream_create(void)
 }
 void vvc355_stream_destroy(void *stream) { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }
 void vvc355_stream_sync(void *stream) { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+void vvc355_graph_begin(void *stream) { HIP_CHECK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal)); }
+void *vvc355_graph_end(void *stream)
+{
+    hipGraph_t g;
+    hipGraphExec_t e;
+    HIP_CHECK(hipStreamEndCapture((hipStream_t)stream, &g));
+    HIP_CHECK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(g));
+    return (void *)e;
+}
+void vvc355_graph_launch(void *graph_exec, void *stream) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream)); }
+void vvc355_graph_destroy(void *graph_exec) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
 const char *vvc355_version(void) { return "vvc_mi355 0.1 (gfx950)"; }
 
 } // extern "C"

@@ -40,6 +40,13 @@ void  vvc355_download(void *host, const void *dev, size_t bytes);
 void *vvc355_stream_create(void);
 void  vvc355_stream_destroy(void *stream);
 void  vvc355_stream_sync(void *stream);          /* NULL = the default stream */
+/* A frame's launch sequence as a hipGraph: every batched / stage-driver entry called on `stream` between begin and end is
+ * recorded instead of run (stream = one made by vvc355_stream_create, not the default stream); the returned executable graph
+ * replays the whole sequence with one launch.  The descriptors the entries were given must stay alive and unchanged. */
+void  vvc355_graph_begin(void *stream);
+void *vvc355_graph_end(void *stream);
+void  vvc355_graph_launch(void *graph_exec, void *stream);
+void  vvc355_graph_destroy(void *graph_exec);
 const char *vvc355_version(void);
 
 /* ------------------------------------------------------------------ constant tables (tables.cpp) */
