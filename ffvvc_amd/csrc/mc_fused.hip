@@ -575,21 +575,28 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
     //   D = (s0 >> 4) - (s1 >> 4), TH = (gh0 + gh1) >> 1, TV = (gv0 + gv1) >> 1, GHD = gh0 - gh1, GVD = gv0 - gv1
     // with gh / gv the gradients of prof_grad_filter (:135).  The reference replicates the rings of s and of every gradient plane
     // (pad_int16, vvcdsp.c:29); replicating D, TH, TV is the same thing, and GHD / GVD / s are only read inside the block.
-    int16_t *pD = L.grad[0], *pTH = L.grad[1], *pTV = L.grad[2], *pGHD = L.grad[3], *pGVD = L.grad[4];
+    int16_t *pD = L.grad[0], *pTH = L.grad[1], *pTV = L.grad[2];
+    // The lane keeps the samples it interpolated (v0 / v1: column lane & 15, rows 2g, 2g + 1, 2g + 8, 2g + 9): their own values,
+    // GHD and GVD never go through LDS — only what other lanes read (D, TH, TV for the window sums) is stored.
+    int ghd[4], gvd[4];
     {
         const int x = (lane & 15) + 1;
-        if (x <= w)
-            for (int y = (lane >> 4) + 1; y <= h; y += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1) + 1;
+            ghd[i] = gvd[i] = 0;
+            if (x <= w && y <= h) {
                 const int o = y * kGs + x;
                 const int gh0 = (smp0[o + 1] >> 6) - (smp0[o - 1] >> 6), gv0 = (smp0[o + kGs] >> 6) - (smp0[o - kGs] >> 6);
                 const int gh1 = (smp1[o + 1] >> 6) - (smp1[o - 1] >> 6), gv1 = (smp1[o + kGs] >> 6) - (smp1[o - kGs] >> 6);
                 // the reference stores the gradients as int16 (no narrowing happens: |g| <= 2^9)
-                pD[o] = (int16_t)((smp0[o] >> 4) - (smp1[o] >> 4));
+                pD[o] = (int16_t)((v0[i] >> 4) - (v1[i] >> 4));
                 pTH[o] = (int16_t)((gh0 + gh1) >> 1);
                 pTV[o] = (int16_t)((gv0 + gv1) >> 1);
-                pGHD[o] = (int16_t)(gh0 - gh1);
-                pGVD[o] = (int16_t)(gv0 - gv1);
+                ghd[i] = gh0 - gh1;
+                gvd[i] = gv0 - gv1;
             }
+        }
     }
     wave_sync();
     // replicate rings: left / right columns first, then whole top / bottom rows
@@ -611,50 +618,54 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
     // a lane sums one 3x3 quarter of the 6x6 window, two quad exchanges finish the sums, then it writes one row of the sub-block
     const int sbw = w >> 2, nsb = sbw * (h >> 2);
     const int sb = lane >> 2, q = lane & 3;
-    if (sb >= nsb)
-        return;                                          // whole quads leave together
-    const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
-    int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
+    if (sb < nsb) {
+        const int by = (sb / sbw) * 4, bx = (sb % sbw) * 4;
+        int sgx2 = 0, sgy2 = 0, sgxgy = 0, sgxdi = 0, sgydi = 0;
+        {
+            const int o0 = (by + 3 * (q >> 1)) * kGs + bx + 3 * (q & 1);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int o = o0 + j * kGs + i;
+                    const int diff = pD[o], th = pTH[o], tv = pTV[o];
+                    sgx2 += abs(th);
+                    sgy2 += abs(tv);
+                    sgxgy += sign_of(tv) * th;
+                    sgxdi += -sign_of(th) * diff;
+                    sgydi += -sign_of(tv) * diff;
+                }
+        }
+#pragma unroll
+        for (int m = 2; m >= 1; m >>= 1) {
+            sgx2 += __shfl_xor(sgx2, m, 4);
+            sgy2 += __shfl_xor(sgy2, m, 4);
+            sgxgy += __shfl_xor(sgxgy, m, 4);
+            sgxdi += __shfl_xor(sgxdi, m, 4);
+            sgydi += __shfl_xor(sgydi, m, 4);
+        }
+        const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;
+        const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
+        if (q == 0)
+            L.sad[sb] = (vx & 0xffff) | (vy << 16);       // the DMVR cost array is dead by now: (vx, vy) of sub-block sb
+    }
+    wave_sync();
+    // apply_bdof_min_block (:267) on the lane's own four samples
     {
-        const int o0 = (by + 3 * (q >> 1)) * kGs + bx + 3 * (q & 1);
+        const int sh = 15 - BD, off = 1 << (sh - 1);
+        const int x = lane & 15;
+        uint8_t *dst0 = (uint8_t *)job->dst;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int o = o0 + j * kGs + i;
-                const int diff = pD[o], th = pTH[o], tv = pTV[o];
-                sgx2 += abs(th);
-                sgy2 += abs(tv);
-                sgxgy += sign_of(tv) * th;
-                sgxdi += -sign_of(th) * diff;
-                sgydi += -sign_of(tv) * diff;
-            }
+        for (int i = 0; i < 4; i++) {
+            const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+            if (x >= w || y >= h)
+                continue;
+            const int vv = L.sad[(y >> 2) * sbw + (x >> 2)];
+            const int vx = (int16_t)vv, vy = vv >> 16;
+            const int p = (v0[i] + off + v1[i] + vx * ghd[i] + vy * gvd[i]) >> sh;
+            gst_at<px_t>(dst0, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(px_t)), (px_t)clip_px<BD>(p));
+        }
     }
-#pragma unroll
-    for (int m = 2; m >= 1; m >>= 1) {
-        sgx2 += __shfl_xor(sgx2, m, 4);
-        sgy2 += __shfl_xor(sgy2, m, 4);
-        sgxgy += __shfl_xor(sgxgy, m, 4);
-        sgxdi += __shfl_xor(sgxdi, m, 4);
-        sgydi += __shfl_xor(sgydi, m, 4);
-    }
-    const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;
-    const int vy = sgy2 > 0 ? clip3(((sgydi * 4) - ((vx * sgxgy) >> 1)) >> ilog2(sgy2), -15, 15) : 0;
-    const int sh = 15 - BD, off = 1 << (sh - 1);
-    const int py = by + q;
-    uint8_t *dst0 = (uint8_t *)job->dst;
-    const uint32_t drow = (uint32_t)__mul24(py, job->dst_stride);
-    int out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int o = (py + 1) * kGs + bx + k + 1;
-        const int corr = vx * pGHD[o] + vy * pGVD[o];
-        out[k] = clip_px<BD>((smp0[o] + off + smp1[o] + corr) >> sh);
-    }
-    if (BD > 8)
-        gst_at<uint2>(dst0, drow + bx * 2, make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16)));
-    else
-        gst_at<uint32_t>(dst0, drow + bx, (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24));
 }
 
 // both references at motion mv: windows through clamped coordinates, then the separable interpolation of interp_block
