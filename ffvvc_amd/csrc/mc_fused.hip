@@ -587,8 +587,11 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
             ghd[i] = gvd[i] = 0;
             if (x <= w && y <= h) {
                 const int o = y * kGs + x;
-                const int gh0 = (smp0[o + 1] >> 6) - (smp0[o - 1] >> 6), gv0 = (smp0[o + kGs] >> 6) - (smp0[o - kGs] >> 6);
-                const int gh1 = (smp1[o + 1] >> 6) - (smp1[o - 1] >> 6), gv1 = (smp1[o + kGs] >> 6) - (smp1[o - kGs] >> 6);
+                // rows come in pairs (2g, 2g + 1): one vertical neighbour is the lane's own other sample of the pair
+                const int up0 = (i & 1) ? v0[i - 1] : (int)smp0[o - kGs], dn0 = (i & 1) ? (int)smp0[o + kGs] : v0[i + 1];
+                const int up1 = (i & 1) ? v1[i - 1] : (int)smp1[o - kGs], dn1 = (i & 1) ? (int)smp1[o + kGs] : v1[i + 1];
+                const int gh0 = (smp0[o + 1] >> 6) - (smp0[o - 1] >> 6), gv0 = (dn0 >> 6) - (up0 >> 6);
+                const int gh1 = (smp1[o + 1] >> 6) - (smp1[o - 1] >> 6), gv1 = (dn1 >> 6) - (up1 >> 6);
                 // the reference stores the gradients as int16 (no narrowing happens: |g| <= 2^9)
                 pD[o] = (int16_t)((v0[i] >> 4) - (v1[i] >> 4));
                 pTH[o] = (int16_t)((gh0 + gh1) >> 1);
