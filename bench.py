@@ -5,9 +5,14 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 
 ``python -m torch.distributed.run`` with one rank per GPU.  A *step* is one pass of every stage of the hot path over one
 synthetic 8K (7680x4320, 4:2:0, 10-bit) random-access frame = 2040 CTUs of 128x128, all inputs resident in HBM:
 
-    inter prediction (8-tap luma / 4-tap chroma hv from two references, averaged; fused) -> intra prediction (intra CTUs)
-    -> inverse transform + residual add -> LMCS inverse luma map -> deblock (vertical, horizontal; luma + chroma)
-    -> SAO -> ALF (luma classify+filter, chroma, cross-component)
+    inter prediction (bi-prediction with DMVR search + 8-tap luma MC + BDOF, then 4-tap chroma at the refined motion)
+    -> intra prediction (intra CTUs) -> dequant + inverse transform + residual add -> LMCS inverse luma map
+    -> boundary strengths from the side tables -> deblock (vertical, horizontal; luma + chroma) -> SAO
+    -> ALF (luma classify + filter, chroma, cross-component); the loop filters through their table-driven stage drivers
+
+Timing: W warm-up steps; an untimed pass of K steps with HIP events around every stage (the ``stages`` breakdown and which
+stage dominates); then the timed region: exactly K steps between barrier + synchronize, HIP events around the dominant
+stage only (``roofline``).  ``--graph`` replays the step as one captured hipGraph in the timed region instead.
 
 Frames are independent, so ranks share nothing: weak scaling, no data-path collective (torch.distributed is used only
 for the barrier and the max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line.
