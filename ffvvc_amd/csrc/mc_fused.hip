@@ -492,10 +492,13 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
                     uint32_t va[8], vb[8];
 #pragma unroll
                     for (int x = 0; x < 8; x++) { va[x] = ar[x]; vb[x] = br[x]; }      // 16 samples; both planes are 20 wide, so in range for w = 8 too
+                    // (w is 8 or 16: a wave-uniform branch instead of eight per-lane selects)
 #pragma unroll
-                    for (int x = 0; x < 8; x++)
-                        if (2 * x < w)
-                            acc = __builtin_amdgcn_sad_u16(va[x], vb[x], acc);
+                    for (int x = 0; x < 4; x++) acc = __builtin_amdgcn_sad_u16(va[x], vb[x], acc);
+                    if (w > 8) {
+#pragma unroll
+                        for (int x = 4; x < 8; x++) acc = __builtin_amdgcn_sad_u16(va[x], vb[x], acc);
+                    }
                 }
             }
             acc += __shfl_xor(acc, 1, 64);
