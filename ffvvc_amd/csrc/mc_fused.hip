@@ -431,8 +431,7 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
                 const uint32_t p0 = *(const uint32_t *)(win + r * kWinW), p1 = *(const uint32_t *)(win + r * kWinW + 2);
                 if (mx) {
                     t0 = (dot2(p0, hc, 0) + off1) >> sh1;
-                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, 0) + off1) >> sh1;
-                    if (my) { t0 = (int16_t)t0; t1 = (int16_t)t1; }
+                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, 0) + off1) >> sh1;     // <= 2^(bd - sh1 + 4) = 1024: the int16 store of the reference changes nothing
                 } else {
                     t0 = p0 & 0xffff; t1 = p0 >> 16;
                 }
