@@ -426,12 +426,40 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
             const uint32_t hc = pack16(16 - mx, mx);
             const uint16_t *win = L.win[i] + 2 * cp;
             const int r0 = seg * rps, r1 = min(r0 + rps, ph);
+            if constexpr (BD <= 10) {
+                // Up to 10 bits the four cases of inter.dmvr[!!my][!!mx] are one formula: with a zero fraction the two-tap filter is
+                // 16 x sample, and (16 s + off1) >> sh1 = s << (10 - bd), ((16 t + 8) >> 4) = t exactly — so the general
+                // horizontal-then-vertical form reproduces the copy, the h-only and the v-only variants bit for bit, without the
+                // divergent branches (the two references of a wave have different fractions).  At 12 bits the v-only variant rounds
+                // once where the general form would round twice: the case analysis stays (below).
+                const uint32_t vc = pack16(16 - my, my);
+                auto hstage = [&](int r, int &t0, int &t1) {
+                    const uint32_t p0 = *(const uint32_t *)(win + r * kWinW), p1 = *(const uint32_t *)(win + r * kWinW + 2);
+                    t0 = (dot2(p0, hc, off1)) >> sh1;
+                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, off1)) >> sh1;
+                };
+                int a0, a1;
+                hstage(r0, a0, a1);
+                for (int r = r0; r < r1; r++) {
+                    int b0, b1;
+                    hstage(r + 1, b0, b1);
+                    const int v0 = dot2(pack16(a0, b0), vc, 8) >> 4, v1 = dot2(pack16(a1, b1), vc, 8) >> 4;
+                    const int e = r * kBilP + 2 * cp;
+                    *(uint32_t *)&L.bil[i][0][e] = pack16(v0, v1);
+                    // shifted copy: element j holds natural element j + 1 (slot -1 of row 0 lands in the 4 spare elements).  Two
+                    // 16-bit stores on purpose (volatile): merged into one 32-bit store at a 2-byte aligned address they are slow
+                    volatile int16_t *sh_copy = L.bil[i][1];
+                    sh_copy[e + 3] = (int16_t)v0;
+                    sh_copy[e + 4] = (int16_t)v1;
+                    a0 = b0; a1 = b1;
+                }
+            } else {
             // horizontal stage of row r for the two columns
             auto hstage = [&](int r, int &t0, int &t1) {
                 const uint32_t p0 = *(const uint32_t *)(win + r * kWinW), p1 = *(const uint32_t *)(win + r * kWinW + 2);
                 if (mx) {
                     t0 = (dot2(p0, hc, 0) + off1) >> sh1;
-                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, 0) + off1) >> sh1;     // <= 2^(bd - sh1 + 4) = 1024: the int16 store of the reference changes nothing
+                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, 0) + off1) >> sh1;     // <= 1024: the int16 store of the reference changes nothing
                 } else {
                     t0 = p0 & 0xffff; t1 = p0 >> 16;
                 }
@@ -445,15 +473,14 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
                 if (mx && my)      { v0 = ((16 - my) * a0 + my * b0 + 8) >> 4;         v1 = ((16 - my) * a1 + my * b1 + 8) >> 4; }
                 else if (mx)       { v0 = a0;                                           v1 = a1; }
                 else if (my)       { v0 = ((16 - my) * a0 + my * b0 + off1) >> sh1;     v1 = ((16 - my) * a1 + my * b1 + off1) >> sh1; }
-                else if (BD > 10)  { v0 = (a0 + (1 << (BD - 11))) >> (BD - 10);         v1 = (a1 + (1 << (BD - 11))) >> (BD - 10); }
-                else               { v0 = a0 << (10 - BD);                              v1 = a1 << (10 - BD); }
+                else               { v0 = (a0 + (1 << (BD - 11))) >> (BD - 10);         v1 = (a1 + (1 << (BD - 11))) >> (BD - 10); }
                 const int e = r * kBilP + 2 * cp;
                 *(uint32_t *)&L.bil[i][0][e] = pack16(v0, v1);
-                // shifted copy: element j holds natural element j + 1 (slot -1 of row 0 lands in the 4 spare elements)
                 L.bil[i][1][e + 3] = (int16_t)v0;
                 L.bil[i][1][e + 4] = (int16_t)v1;
                 if (my) { a0 = b0; a1 = b1; }
                 else if (r + 1 < r1) hstage(r + 1, a0, a1);
+            }
             }
         }
     }
