@@ -432,26 +432,28 @@ __device__ __forceinline__ void dmvr_refine(const vvc355_bipred_job *job, Bipred
                 // horizontal-then-vertical form reproduces the copy, the h-only and the v-only variants bit for bit, without the
                 // divergent branches (the two references of a wave have different fractions).  At 12 bits the v-only variant rounds
                 // once where the general form would round twice: the case analysis stays (below).
-                const uint32_t vc = pack16(16 - my, my);
-                auto hstage = [&](int r, int &t0, int &t1) {
+                // ... and both columns of the lane's pair go through packed 16-bit arithmetic: every intermediate is at most
+                // 16 x (2^bd - 1) + 8 < 2^16
+                typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+                auto PK = [](uint32_t v) { return __builtin_bit_cast(pku16, v); };
+                auto SP = [](int v) { return pku16{ (unsigned short)v, (unsigned short)v }; };
+                const pku16 MX = SP(mx), MX16 = SP(16 - mx), MY = SP(my), MY16 = SP(16 - my), OFF1 = SP(off1), EIGHT = SP(8);
+                auto hstage = [&](int r) -> pku16 {
                     const uint32_t p0 = *(const uint32_t *)(win + r * kWinW), p1 = *(const uint32_t *)(win + r * kWinW + 2);
-                    t0 = (dot2(p0, hc, off1)) >> sh1;
-                    t1 = (dot2(__builtin_amdgcn_alignbit(p1, p0, 16), hc, off1)) >> sh1;
+                    return (PK(p0) * MX16 + PK(__builtin_amdgcn_alignbit(p1, p0, 16)) * MX + OFF1) >> SP(sh1);
                 };
-                int a0, a1;
-                hstage(r0, a0, a1);
+                pku16 a = hstage(r0);
+                volatile int16_t *sh_copy = L.bil[i][1];
                 for (int r = r0; r < r1; r++) {
-                    int b0, b1;
-                    hstage(r + 1, b0, b1);
-                    const int v0 = dot2(pack16(a0, b0), vc, 8) >> 4, v1 = dot2(pack16(a1, b1), vc, 8) >> 4;
+                    const pku16 b = hstage(r + 1);
+                    const pku16 v = (a * MY16 + b * MY + EIGHT) >> SP(4);
                     const int e = r * kBilP + 2 * cp;
-                    *(uint32_t *)&L.bil[i][0][e] = pack16(v0, v1);
+                    *(uint32_t *)&L.bil[i][0][e] = __builtin_bit_cast(uint32_t, v);
                     // shifted copy: element j holds natural element j + 1 (slot -1 of row 0 lands in the 4 spare elements).  Two
                     // 16-bit stores on purpose (volatile): merged into one 32-bit store at a 2-byte aligned address they are slow
-                    volatile int16_t *sh_copy = L.bil[i][1];
-                    sh_copy[e + 3] = (int16_t)v0;
-                    sh_copy[e + 4] = (int16_t)v1;
-                    a0 = b0; a1 = b1;
+                    sh_copy[e + 3] = (int16_t)v.x;
+                    sh_copy[e + 4] = (int16_t)v.y;
+                    a = b;
                 }
             } else {
             // horizontal stage of row r for the two columns
