@@ -50,7 +50,13 @@ def test_bipred_frame(dev, orc, bd):
         else:
             mv0 = [int(v) for v in rng.integers(-200, 201, size=2)]
             mv1 = [int(v) for v in rng.integers(-200, 201, size=2)]
-        dmvr = int(rng.random() < 0.7)
+        # whole-sample components (zero fractions) in every combination: the DMVR bilinear stage has one variant per (!!my, !!mx)
+        z = i % 9 if kind >= 2 else 0
+        if z in (5, 7):
+            mv0[0], mv1[0] = mv0[0] // 16 * 16, (mv1[0] // 16 * 16 if z == 7 else mv1[0])
+        if z in (6, 7):
+            mv0[1], mv1[1] = (mv0[1] // 16 * 16 if z == 7 else mv0[1]), mv1[1] // 16 * 16
+        dmvr = int(rng.random() < 0.7 or z in (5, 6, 7))
         bdof = int(rng.random() < 0.6)
         if kind == 0:
             dmvr = bdof = 1
