@@ -14,8 +14,9 @@ Timing: W warm-up steps; an untimed pass of K steps with HIP events around every
 stage dominates); then the timed region: exactly K steps between barrier + synchronize, HIP events around the dominant
 stage only (``roofline``).  ``--graph`` replays the step as one captured hipGraph in the timed region instead.
 
-Frames are independent, so ranks share nothing: weak scaling, no data-path collective (torch.distributed is used only
-for the barrier and the max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line.
+Frames are independent, so ranks share nothing: weak scaling, no data-path collective and no RCCL (torch.distributed over gloo
+carries one barrier and the max-over-ranks of the elapsed time).  ``python bench.py --gpus N`` on its own starts the N ranks
+itself (fresh child processes, one per GPU, before anything touches HIP).  Rank 0 prints ONE JSON line.
 
 PyTorch is plumbing here (device memory, streams, events, the rendezvous); every timed kernel is a hand-written HIP
 kernel reached through the C ABI (include/vvc_mi355.h).  The CPU oracle is timed separately, as ``cpu_baseline``.
@@ -680,7 +681,103 @@ def cpu_baseline(root, fr, budget_s):
     }
 
 
-def parse_args():
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``--gpus N`` with no rendezvous in the environment: start N fresh rank processes, one per GPU, and relay rank 0's JSON line.
+
+    The parent never imports torch and never makes a HIP call, and the children are new processes started with subprocess (never
+    an exec of a process that has touched the GPU).  Any failing rank fails the run: the others are stopped by PID and the exit code
+    is non-zero.  Under ``python -m torch.distributed.run`` the environment already carries the rendezvous and this is not used."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # rank 0's stdout never blocks on a full pipe
+    reader.start()
+    failed = None
+    while failed is None:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+        elif all(rc == 0 for rc in rcs):
+            break
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                       # exact PIDs of the children started above
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit(f"bench.py: rank {failed[0]} of {n} exited with code {failed[1]}")
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else ""
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != n:
+        raise SystemExit(f"bench.py: rank 0 reports n_gpus = {line.get('n_gpus')}, expected {n}")
+    print(lines[-1], flush=True)
+
+
+def rendezvous(args):
+    """(world, rank, local_rank, dist): one process per GPU; torch.distributed (gloo: the ranks exchange one barrier and one float,
+    there is no data-path collective and no RCCL traffic) only when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: launch with --gpus equal to the number of ranks")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return world, rank, local_rank, dist
+
+
+def stub_main(args, world, rank, dist):
+    """The bench protocol around a host sleep instead of the GPU chain (TEST AID, --stub-step-ms): warm-up, barrier, exactly K timed
+    steps, barrier, max over ranks, one JSON line from rank 0."""
+    import torch
+    step = lambda: time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))      # noqa: E731  (rank r is slower: the max must pick the last rank)
+    for _ in range(args.warmup):
+        step()
+    sharding.barrier(dist, world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    sharding.barrier(dist, world)
+    elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (host sleep, no GPU work)", "stub": True, "value": world * args.steps / elapsed, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "stub"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -698,28 +795,31 @@ def parse_args():
                     help="profiling aid: deblock from host-built edge jobs (vvc355_deblock_batch) instead of the stage driver")
     ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
-    return ap.parse_args()
+    ap.add_argument("--stub-step-ms", type=float, default=None,
+                    help="TEST AID: replace the GPU chain by a host sleep of this many ms per step (exercises the launcher, the rendezvous, "
+                         "the barrier / max-over-ranks protocol and the JSON line on a machine without a GPU); the line says \"stub\": true")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
     global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES
     SAO_TABLES = not args.sao_jobs
     ALF_TABLES = not args.alf_jobs
     DEBLOCK_JOBS = args.deblock_jobs
     MC_TOOLS = args.mc_tools & 3
     AFFINE_FRAC = args.affine_frac
+    world, rank, local_rank, dist = rendezvous(args)
+    if args.stub_step_ms is not None:
+        return stub_main(args, world, rank, dist)
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     lib = abi.load()
     lib.vvc355_set_device(local_rank)
 
@@ -782,7 +882,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cuda")
+    elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cpu")
 
     if rank == 0:
         stage_ms = dict(breakdown)

@@ -761,6 +761,14 @@ struct BipredLdsLight {
     int16_t tmpT[16 * kTmpP];
 };
 
+#include "mc_tools.hpp"
+
+// what one wave of a luma launch needs: the general path's planes or the tools path's (same footprint, 5.6 KB: 28 waves per CU)
+union BipredLdsAll {
+    BipredLds gen;
+    ToolsLds<16, 16> tools;
+};
+
 template <int BD, bool TOOLS>
 __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredLds &L, int lane)
 {
@@ -768,6 +776,16 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
         return;                                          // contract: a chroma-only launch holds chroma jobs
     const int uni = job->pred_flag == 1 || job->pred_flag == 2;        // luma_mc_uni / chroma_mc_uni: one list, no DMVR / BDOF
     const int w = job->w, h = job->h, chroma = job->chroma, dmvr = job->dmvr && !uni;
+    if constexpr (TOOLS) {
+        // bi-predicted luma sub-blocks with DMVR and / or BDOF (8 or 16 on a side, the only shapes those tools run on): mc_tools.hpp
+        if (!chroma && !uni && (job->dmvr || job->bdof) && (w == 8 || w == 16) && (h == 8 || h == 16)) {
+            if (w == 16 && h == 16)     bipred_tools<BD, 16, 16>(job, *(ToolsLds<16, 16> *)&L, lane);
+            else if (w == 16)           bipred_tools<BD, 16, 8>(job, *(ToolsLds<16, 8> *)&L, lane);
+            else if (h == 16)           bipred_tools<BD, 8, 16>(job, *(ToolsLds<8, 16> *)&L, lane);
+            else                        bipred_tools<BD, 8, 8>(job, *(ToolsLds<8, 8> *)&L, lane);
+            return;
+        }
+    }
     const int lw = 31 - __builtin_clz(w);
     vvc355_bipred_result *rec = (vvc355_bipred_result *)job->rec;
     int mv[4] = { job->mv[0], job->mv[1], job->mv[2], job->mv[3] };
@@ -867,7 +885,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
 template <int BD, bool TOOLS>
 __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__restrict__ jobs, int n_jobs)
 {
-    __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLds, BipredLdsLight>::type lds_all[4];
+    __shared__ __attribute__((aligned(16))) typename std::conditional<TOOLS, BipredLdsAll, BipredLdsLight>::type lds_all[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ji = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
     if (ji >= n_jobs)
@@ -1013,3 +1031,4 @@ extern "C" void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bi
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_chroma_pair_kernel<BD>), dim3((n_pairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
     HIP_CHECK(hipGetLastError());
 }
+

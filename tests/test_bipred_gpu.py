@@ -122,7 +122,18 @@ def test_bipred_frame(dev, orc, bd):
     for c in range(3):
         got = d_out[c].to_host(want[c].dtype, want[c].shape)
         bad = np.argwhere(got != want[c])
-        assert len(bad) == 0, f"component {c}: {len(bad)} samples differ, first at {bad[0].tolist()}"
+        if len(bad):
+            # which blocks, with which tools: the pattern of a failure says more than its first sample
+            sh = 1 if c else 0
+            rows = []
+            for i, (x, y, w, h) in enumerate(blocks):
+                m = got[y >> sh:(y + h) >> sh, x >> sh:(x + w) >> sh] != want[c][y >> sh:(y + h) >> sh, x >> sh:(x + w) >> sh]
+                if m.any():
+                    j = host_jobs[3 * i][0]
+                    ys_, xs_ = np.nonzero(m)
+                    rows.append(f"blk{i} {x},{y} {w}x{h} dmvr={j.dmvr} bdof={j.bdof}->{exp_rec[i][4]} wf={j.weight_flag} pf={j.pred_flag} mv={list(j.mv)}->"
+                                f"{exp_rec[i][:4].tolist()} n={m.sum()} cols={sorted(set(xs_.tolist()))} rows={sorted(set(ys_.tolist()))}")
+            assert False, f"component {c}: {len(bad)} samples differ in {len(rows)} blocks:\n" + "\n".join(rows[:40])
     # the case mix must reach every branch: searches, early terminations, BDOF on and switched off by DMVR
     dm = np.array([hj[0].dmvr for hj in host_jobs[::3]], bool)
     assert np.any(exp_rec[dm, 6] == 1) and np.any(exp_rec[dm, 6] == 0)
