@@ -45,8 +45,7 @@ MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted bl
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CTB = 128
 # what the chain still lacks of BASELINE.json configs[3] (8K random-access, full in-loop filter chain)
-MISSING = ["intra wavefront ordering (intra TUs are launched as one independent batch)",
-           "affine (PROF) blocks: batched stage exists (vvc355_affine_batch, bench.py --affine-frac), not part of the metric's frame mix",
+MISSING = ["affine (PROF) blocks: batched stage exists (vvc355_affine_batch, bench.py --affine-frac), not part of the metric's frame mix",
            "GPM / CIIP blocks in the MC stage (slots exist; the frame mix is regular bi-prediction only)"]
 
 TC_TABLE = [0] * 18 + [3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10, 10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45,
@@ -84,7 +83,7 @@ class Frame:
         self.host = {}        # data_ptr -> host copy of every uploaded table (what the `verified` leg mirrors for the oracle)
         self.noise = False
 
-    def picture(self, c, pad, like=None, shift=(0, 0), sigma=4.0):
+    def picture(self, c, pad, like=None, shift=(0, 0), sigma=2.0):
         """One plane of a reference picture (component c) with a `pad`-sample apron; `like` = displaced noisy copy of that plane."""
         torch = self.torch
         w, h = self.dims[c]
@@ -278,35 +277,13 @@ def build_chain(lib, torch, fr):
 
         chain.append(Stage("inter_pred_affine_prof", f"affine_kernel<{bd}>", launch_affine, len(xa0) * (256 + 128) * 3 * isz))
 
-    # ---------------------------------------------------------------- intra prediction of the intra CTUs (16x16 luma, 8x8 chroma TUs)
-    ij = []
-    for c, (w, h) in enumerate(fr.dims):
-        bs = 16 if c == 0 else 8
-        cs = CTB if c == 0 else CTB // 2
-        x0, y0 = batch.block_grid(w // bs * bs, h // bs * bs, bs, bs)
-        intra = ~ctu_inter[(y0 // cs) * fr.ncx + (x0 // cs)]
-        x0, y0 = x0[intra], y0[intra]
-        j = batch.job_array(abi.IntraJob, len(x0))
-        j["plane"], j["stride"] = ptr(rec[c]), fr.pitch(rec[c])
-        j["x"], j["y"], j["w"], j["h"] = x0, y0, bs, bs
-        j["mode"] = rng.choice(np.array([0, 1, 18, 50] + list(range(2, 67))), size=len(x0))
-        j["cb_width"] = j["cb_height"] = bs
-        j["left_avail"] = np.where(x0 > 0, np.minimum(2 * bs, h - y0), 0)
-        j["top_avail"] = np.where(y0 > 0, np.minimum(2 * bs, w - x0), 0)
-        j["plane_w"], j["plane_h"], j["c_idx"] = w, h, c
-        j["cand_up_left"] = (x0 > 0) & (y0 > 0)
-        ij.append(j)
-    # two launches by block area: 16x16 luma TUs (a wave per block), 8x8 chroma TUs of both planes (half a wave per block)
-    intra_luma, intra_chroma = ij[0], np.concatenate(ij[1:])
-    d_il, d_ic = fr.upload(intra_luma.view(np.uint8)), fr.upload(intra_chroma.view(np.uint8))
-    n_il, n_ic = len(intra_luma), len(intra_chroma)
-    intra_samples = sum(int(len(j)) * int(j["w"][0]) ** 2 for j in ij)
-
-    def launch_intra(st):
-        lib.vvc355_intra_pred_batch(st, bd, ptr(d_il), n_il, 8)
-        lib.vvc355_intra_pred_batch(st, bd, ptr(d_ic), n_ic, 6)
-
-    chain.append(Stage("intra_pred", f"intra_pred_kernel<{bd}, *>", launch_intra, intra_samples * isz))
+    # ---------------------------------------------------------------- the intra CTUs: a random partition into coding units, flattened into
+    # the RECON stage driver's per-CTU command lists (tests/recon_cases.py mirrors what the parse stage leaves per CTU); their
+    # transform blocks go through the batched transform stage with store_coeffs (residuals in place), the predictions and
+    # the residual adds through the in-order wavefront pass further down
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import recon_cases
+    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.8, 0.25))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape
@@ -326,6 +303,8 @@ def build_chain(lib, torch, fr):
             ox, oy = np.meshgrid(np.arange(0, q, n), np.arange(0, q, n))
             x0 = (cx0[:, None] + qx + ox.ravel()[None, :]).ravel()
             y0 = (cy0[:, None] + qy + oy.ravel()[None, :]).ravel()
+            keep = ctu_inter[(y0 // cs) * fr.ncx + (x0 // cs)]         # the intra CTUs have their own transform blocks (below)
+            x0, y0 = x0[keep], y0[keep]
             j = batch.job_array(abi.ItxJob, len(x0))
             lg = int(np.log2(n))
             j["coeffs"] = coeff_off + np.arange(len(x0), dtype=np.int64) * (n * n * 4)
@@ -390,6 +369,126 @@ def build_chain(lib, torch, fr):
         return len(idx), bad
 
     chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz), writes=rec, check=check_itx))
+
+    # ---------------------------------------------------------------- transform blocks of the intra CTUs: scaling process (+ LFNST on a
+    # fifth of the luma blocks) + inverse transform with the transform types derived on the device (implicit MTS), residuals left
+    # in place for the RECON pass.  Levels are restored from a pristine copy at the start of every step (the stage works in place).
+    itb = np.array(work.tbs, dtype=np.int64).reshape(-1, 6)        # c_idx, x0, y0, w, h, element offset
+    n_tb = len(itb)
+    rng_t = np.random.default_rng(0x5EED0EC1)
+    lev_mag = (-torch.log(torch.rand(max(1, work.resid_len), device="cuda", generator=fr.gen).clamp_min(1e-9)) * 1.1).floor().to(torch.int32)
+    levels0 = lev_mag * (torch.randint(0, 2, (max(1, work.resid_len),), device="cuda", generator=fr.gen, dtype=torch.int32) * 2 - 1)
+    res = torch.zeros_like(levels0)
+    fr.keep += [levels0, res]
+    tw, th, tc = itb[:, 3], itb[:, 4], itb[:, 0]
+    tlw, tlh = np.log2(tw).astype(np.int64), np.log2(th).astype(np.int64)
+    use_lfnst = (tc == 0) & (tw >= 4) & (th >= 4) & (rng_t.random(n_tb) < 0.2)
+    itj = batch.job_array(abi.ItxJob, n_tb)
+    itj["coeffs"] = ptr(res) + itb[:, 5] * 4
+    itj["log2_w"], itj["log2_h"], itj["range"], itj["bd"], itj["store_coeffs"], itj["c_idx"] = tlw, tlh, 15, bd, 1, tc
+    inzw = 1 + (rng_t.random(n_tb) * np.minimum(tw, 16)).astype(np.int64)
+    inzh = 1 + (rng_t.random(n_tb) * np.minimum(th, 16)).astype(np.int64)
+    lf_n = np.where((tw >= 8) & (th >= 8), 8, 4)
+    itj["nzw"], itj["nzh"] = np.where(use_lfnst, lf_n, inzw), np.where(use_lfnst, lf_n, inzh)
+    itj["dq_flags"] = np.where(use_lfnst, 0, 1 | (rng_t.integers(0, 2, size=n_tb) << 1))
+    itj["dq_qp"], itj["log2_matrix_size"], itj["dc"] = rng_t.integers(22, 38, size=n_tb), 1, -1
+    itj["mts_flags"], itj["tu_flags"] = abi.ITX_DERIVE_TYPE, abi.TU_MTS_ENABLED | abi.TU_INTRA
+    itj["lfnst_idx"] = np.where(use_lfnst, rng_t.integers(1, 3, size=n_tb), 0)
+    # the levels of a block live inside its scan window (LFNST blocks: the ifirst 16 positions of the 4x4 diagonal scan)
+    win_w, win_h = np.where(use_lfnst, np.minimum(tw, 4), inzw), np.where(use_lfnst, np.minimum(th, 4), inzh)
+    lfj = batch.job_array(abi.LfnstJob, int(use_lfnst.sum()))
+    lfi = np.nonzero(use_lfnst)[0]
+    lfj["coeffs"], lfj["log2_w"], lfj["log2_h"] = itj["coeffs"][lfi], tlw[lfi], tlh[lfi]
+    lfj["max_x"], lfj["max_y"], lfj["qp"], lfj["dequant"], lfj["dep_quant"] = win_w[lfi] - 1, win_h[lfi] - 1, itj["dq_qp"][lfi], 1, rng_t.integers(0, 2, size=len(lfi))
+    lfj["bit_depth"], lfj["range"], lfj["log2_matrix_size"], lfj["dc"] = bd, 15, 1, -1
+    lfj["pred_mode_intra"], lfj["lfnst_idx"] = rng_t.integers(-14, 81, size=len(lfi)), itj["lfnst_idx"][lfi]
+    # zero the levels outside the windows (one pass over the pristine copy, host-built imask)
+    imask = np.zeros(max(1, work.resid_len), np.int32)
+    for k in range(n_tb):
+        w_, o_ = int(tw[k]), int(itb[k, 5])
+        m2 = imask[o_:o_ + int(tw[k] * th[k])].reshape(int(th[k]), w_)
+        m2[:int(win_h[k]), :int(win_w[k])] = 1
+    levels0 *= torch.from_numpy(imask).cuda()
+    area_class = np.select([tlw + tlh <= 4, tlw + tlh <= 6, tlw + tlh <= 8, tlw + tlh <= 10], [4, 6, 8, 10], 12)
+    tb_order = np.argsort(area_class, kind="stable")
+    itj_sorted = itj[tb_order]
+    d_tj, d_lj = fr.upload(itj_sorted.view(np.uint8)), fr.upload(lfj.view(np.uint8) if len(lfj) else np.zeros(32, np.uint8))
+    tb_launches, ifirst = [], 0
+    for cls in (4, 6, 8, 10, 12):
+        cnt = int((area_class == cls).sum())
+        if cnt:
+            tb_launches.append((ifirst, cnt, cls))
+        ifirst += cnt
+    n_lj, tjsz = len(lfj), itj.dtype.itemsize
+
+    def launch_intra_tb(st):
+        lib.vvc355_copy_async(st, ptr(res), ptr(levels0), res.numel() * 4)
+        if n_lj:
+            lib.vvc355_lfnst_batch(st, ptr(d_lj), n_lj)
+        for (first_, cnt_, cls_) in tb_launches:
+            lib.vvc355_itx_batch(st, bd, ptr(d_tj) + first_ * tjsz, cnt_, cls_)
+
+    tb_ctu = (itb[:, 2] // CTB) * fr.ncx + itb[:, 1] // CTB
+
+    def check_intra_tb(fc, orc, env):
+        lev = env.snap(levels0)
+        got = env.after[ptr(res)]
+        pick = np.nonzero(np.isin(tb_ctu, env.picks) | (np.arange(n_tb) % 97 == 0))[0]
+        lf_of = {int(i): k for k, i in enumerate(lfi)}
+        bad = 0
+        for k in pick:
+            w_, h_, o_ = int(tw[k]), int(th[k]), int(itb[k, 5])
+            co = lev[o_:o_ + w_ * h_].copy()
+            j = itj[k]
+            if int(k) in lf_of:
+                l = lfj[lf_of[int(k)]]
+                orc.orc_dequant(co.ctypes.data, int(tlw[k]), int(tlh[k]), 0, 0, int(l["max_x"]), int(l["max_y"]), int(l["qp"]), 0, int(l["dep_quant"]), bd, 15, None, 1, -1)
+                orc.orc_ilfnst_transform(co.ctypes.data, w_, h_, int(l["pred_mode_intra"]), int(l["lfnst_idx"]), 15)
+            else:
+                orc.orc_dequant(co.ctypes.data, int(tlw[k]), int(tlh[k]), 0, 0, int(j["nzw"]) - 1, int(j["nzh"]) - 1, int(j["dq_qp"]), 0, (int(j["dq_flags"]) >> 1) & 1, bd, 15, None, 1, -1)
+            t = orc.orc_derive_transform_type(int(j["tu_flags"]), int(j["mts_idx"]), int(j["lfnst_idx"]), int(j["c_idx"]), w_, h_)
+            orc.orc_itx(t & 15, t >> 4, int(tlw[k]), int(tlh[k]), co.ctypes.data, int(j["nzw"]), int(j["nzh"]), 15, bd)
+            bad += not np.array_equal(co, got[o_:o_ + w_ * h_])
+        return len(pick), bad
+
+    if n_tb:
+        chain.append(Stage("intra_tb_dequant_lfnst_itx", f"itx_kernel<{bd}, *> + lfnst_batch_kernel", launch_intra_tb, int(work.resid_len) * (4 + 4),
+                           writes=[res], check=check_intra_tb))
+
+    # ---------------------------------------------------------------- RECON: the intra CTUs' coding units in decoding order (prediction from
+    # what earlier blocks wrote, then the residual), CTUs released in wavefront order
+    if len(work.order):
+        cmds_dev = work.bind(ptr(res))
+        d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(work.order)
+        d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8))
+        d_rslice, d_rcol, d_rrow = fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)
+        rf = work.frame(rec_ptrs, pitches, ptr(d_cmds), ptr(d_ctus), ptr(d_order), ptr(d_rstate), ptr(d_rslice), ptr(d_rcol), ptr(d_rrow))
+        d_rf = fr.upload(np.frombuffer(bytes(rf), np.uint8))
+        fr.keep.append(rf)
+        n_pred = int((work.cmds["kind"] == abi.RECON_PRED).sum() + (work.cmds["kind"] == abi.RECON_CCLM).sum())
+        intra_px = int(((work.cmds["kind"] == abi.RECON_MARK) & (work.cmds["c_idx"] == 0) * 1).astype(bool).sum())    # noqa: F841
+
+        def check_recon(fc, orc, env):
+            # whole picture: the oracle walks the same command lists in decoding order on host copies of the planes
+            orc.orc_recon_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.ReconFrame)]
+            orc.orc_recon_frame_pass.restype = None
+            work_p = [env.before[p_].copy() for p_ in rec_ptrs]
+            for p_, w_ in zip(rec_ptrs, work_p):
+                env.mirror.add(p_, w_)
+            env.mirror.add(ptr(res), env.snap(res))
+            hc = work.bind(env.mirror.host_addr(ptr(res)))
+            env.mirror.add(ptr(d_cmds), hc.view(np.uint8))
+            f = fc.translate(rf, env.mirror, ("plane", "cmds", "ctus", "order", "slice_idx", "ctb_to_col_bd", "ctb_to_row_bd"))
+            f.state = 0
+            orc.orc_recon_frame_pass(bd, ctypes.byref(f))
+            bad = sum(int(not np.array_equal(w_, env.after[p_])) for p_, w_ in zip(rec_ptrs, work_p))
+            env.stats["recon_commands"] = int(len(work.cmds))
+            env.stats["recon_intra_ctus"] = int(len(work.order))
+            return len(work.order), bad
+
+        intra_samples = int(sum(int(c[3]) * int(c[4]) for c in work.cmds[work.cmds["kind"] == abi.RECON_MARK] if c[11] == 0)) * 3 // 2
+        chain.append(Stage("intra_recon_wavefront", f"recon_wavefront_kernel<{bd}>", lambda st: lib.vvc355_recon_frame_pass(st, bd, ptr(d_rf), ctypes.addressof(rf)),
+                           intra_samples * isz, writes=rec, check=check_recon))
 
     # ---------------------------------------------------------------- LMCS inverse luma mapping
     lut = fr.upload(np.sort(rng.integers(0, 1 << bd, size=1 << bd)).astype(np.uint8 if bd == 8 else np.uint16))

@@ -58,6 +58,8 @@ SLOT_SIGNATURES = {
     "itx":                  ("i", "iiiipzzqq"),
     "inv_lfnst_1d":         ("v", "ppiiiii"),
     "dequant":              ("v", "piiiiiiiiiiipii"),
+    "ilfnst_transform":     ("i", "piiiii"),
+    "derive_transform_type": ("i", "iiiiii"),
     "add_residual":         ("v", "ippiiq"),
     "add_residual_joint":   ("v", "ippiiqii"),
     "pred_residual_joint":  ("v", "piiii"),
@@ -86,6 +88,7 @@ RUNTIME_SIGNATURES = {
     "free":           ("v", "p"),
     "upload":         ("v", "ppz"),
     "download":       ("v", "ppz"),
+    "copy_async":     ("v", "pppz"),
     "stream_create":  ("p", ""),
     "stream_destroy": ("v", "p"),
     "stream_sync":    ("v", "p"),
@@ -121,6 +124,9 @@ BATCH_SIGNATURES = {
     "alf_frame_pass":   ("v", "pippp"),
     "deblock_bs_pass":  ("v", "ppp"),
     "alf_frame_work_bytes": ("z", "i"),
+    "lfnst_batch":      ("v", "ppi"),
+    "recon_frame_pass": ("v", "pipp"),
+    "recon_state_bytes": ("z", "i"),
 }
 
 
@@ -218,8 +224,55 @@ class ItxJob(ctypes.Structure):
         ("trh", ctypes.c_uint8), ("trv", ctypes.c_uint8), ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8),
         ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8), ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8),
         ("store_coeffs", ctypes.c_uint8), ("dq_flags", ctypes.c_uint8), ("dq_qp", ctypes.c_uint8), ("log2_matrix_size", ctypes.c_uint8),
-        ("scale_matrix", ctypes.c_uint64), ("dc", ctypes.c_int16), ("pad_", ctypes.c_uint8 * 6),
+        ("scale_matrix", ctypes.c_uint64), ("dc", ctypes.c_int16),
+        ("mts_flags", ctypes.c_uint8), ("tu_flags", ctypes.c_uint8), ("mts_idx", ctypes.c_uint8), ("lfnst_idx", ctypes.c_uint8),
+        ("c_idx", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
     ]
+
+
+class LfnstJob(ctypes.Structure):
+    """Mirror of vvc355_lfnst_job."""
+    _fields_ = [
+        ("coeffs", ctypes.c_uint64), ("scale_matrix", ctypes.c_uint64),
+        ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8), ("max_x", ctypes.c_uint8), ("max_y", ctypes.c_uint8),
+        ("qp", ctypes.c_uint8), ("dequant", ctypes.c_uint8), ("dep_quant", ctypes.c_uint8), ("bit_depth", ctypes.c_uint8),
+        ("range", ctypes.c_uint8), ("log2_matrix_size", ctypes.c_uint8), ("dc", ctypes.c_int16),
+        ("pred_mode_intra", ctypes.c_int8), ("lfnst_idx", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+    ]
+
+
+class ReconCmd(ctypes.Structure):
+    """Mirror of vvc355_recon_cmd (and of the oracle's orc_recon_cmd)."""
+    _fields_ = [
+        ("resid", ctypes.c_uint64),
+        ("x0", ctypes.c_int16), ("y0", ctypes.c_int16), ("w", ctypes.c_int16), ("h", ctypes.c_int16),
+        ("cu_x0", ctypes.c_int16), ("cu_y0", ctypes.c_int16), ("cb_width", ctypes.c_int16), ("cb_height", ctypes.c_int16),
+        ("mode", ctypes.c_int8), ("kind", ctypes.c_uint8), ("c_idx", ctypes.c_uint8), ("ref_idx", ctypes.c_uint8),
+        ("is_mip", ctypes.c_uint8), ("mip_mode", ctypes.c_uint8), ("mip_transposed", ctypes.c_uint8), ("isp_split", ctypes.c_uint8),
+        ("bdpcm_flag", ctypes.c_uint8), ("joint", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6),
+    ]
+
+
+class ReconCtu(ctypes.Structure):
+    """Mirror of vvc355_recon_ctu."""
+    _fields_ = [("first_cmd", ctypes.c_uint32), ("n_cmd", ctypes.c_uint32)]
+
+
+class ReconFrame(ctypes.Structure):
+    """Mirror of vvc355_recon_frame (and of the oracle's orc_recon_frame)."""
+    _fields_ = [
+        ("plane", ctypes.c_uint64 * 3), ("cmds", ctypes.c_uint64), ("ctus", ctypes.c_uint64), ("order", ctypes.c_uint64), ("state", ctypes.c_uint64),
+        ("slice_idx", ctypes.c_uint64), ("ctb_to_col_bd", ctypes.c_uint64), ("ctb_to_row_bd", ctypes.c_uint64),
+        ("stride", ctypes.c_int32 * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
+        ("ctb_height", ctypes.c_int32), ("n_work", ctypes.c_int32),
+        ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("wpp", ctypes.c_uint8), ("collocated", ctypes.c_uint8),
+        ("pad_", ctypes.c_uint8 * 3),
+    ]
+
+
+RECON_MARK, RECON_PRED, RECON_CCLM, RECON_RESID = 0, 1, 2, 3
+TU_MTS_ENABLED, TU_EXPLICIT_MTS_INTRA, TU_ISP, TU_SBT, TU_SBT_HORIZONTAL, TU_SBT_POS, TU_INTRA, TU_MIP = 1, 2, 4, 8, 16, 32, 64, 128
+ITX_DERIVE_TYPE = 1
 
 
 class BipredJob(ctypes.Structure):

@@ -262,22 +262,12 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
 // vvc_intra_template.c:467-592 (edge preparation) + :595-683 (dispatch, PDPC); one workgroup per job.
 // NT = 32: half a wave per block (w*h <= 64), eight blocks per workgroup; NT = 64: one wave per block (w*h <= 256), four per
 // workgroup; both with wave-level synchronisation only.  NT = 256: one workgroup per block.
+// the whole slot for one block, executed by a group of NT lanes (tid = lane's index in the group); arr = four edge arrays in LDS
 template <int BD, int NT>
-__global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs, int n_jobs)
+__device__ void intra_pred_body(const vvc355_intra_job &j, uint16_t (*arr)[kEdgeLen], int *scratch, int tid)
 {
-    constexpr int TBS = 256 / NT;
-    __shared__ uint16_t arr_all[TBS][4][kEdgeLen];
-    __shared__ int scratch_all[TBS][16];
-    const int sub = threadIdx.x / NT;
-    const int ji = xcd_chunked(blockIdx.x, gridDim.x) * TBS + sub;
-    if (ji >= n_jobs)
-        return;
-    uint16_t (*arr)[kEdgeLen] = arr_all[sub];
-    int *scratch = scratch_all[sub];
-    // a wave (or the workgroup) per job: the descriptor comes through the scalar cache; two jobs per wave: per-lane loads
-    const vvc355_intra_job j = NT >= 64 ? load_uniform(jobs + __builtin_amdgcn_readfirstlane(ji)) : jobs[ji];
     const int stride = j.stride / (int)sizeof(typename Px<BD>::type);      // pixels; int keeps the row offsets full-rate 24-bit multiplies
-    const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx, tid = threadIdx.x % NT;
+    const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
     uint8_t *src = (uint8_t *)j.plane + (ptrdiff_t)(__mul24(j.y, stride) + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
     const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
@@ -389,6 +379,21 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
         }
     }
 #undef GETP
+}
+
+template <int BD, int NT>
+__global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job *__restrict__ jobs, int n_jobs)
+{
+    constexpr int TBS = 256 / NT;
+    __shared__ uint16_t arr_all[TBS][4][kEdgeLen];
+    __shared__ int scratch_all[TBS][16];
+    const int sub = threadIdx.x / NT;
+    const int ji = xcd_chunked(blockIdx.x, gridDim.x) * TBS + sub;
+    if (ji >= n_jobs)
+        return;
+    // a wave (or the workgroup) per job: the descriptor comes through the scalar cache; two jobs per wave: per-lane loads
+    const vvc355_intra_job j = NT >= 64 ? load_uniform(jobs + __builtin_amdgcn_readfirstlane(ji)) : jobs[ji];
+    intra_pred_body<BD, NT>(j, arr_all[sub], scratch_all[sub], threadIdx.x % NT);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -561,11 +566,10 @@ __device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, int cx, in
 #undef L
 }
 
+// the whole slot for one block, executed by the workgroup; prm = six ints in LDS (a[2], b[2], k[2])
 template <int BD>
-__global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__restrict__ jobs)
+__device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
 {
-    __shared__ int prm[6];        // a[2], b[2], k[2]
-    const vvc355_cclm_job j = load_uniform(jobs + (blockIdx.x));
     using px_t = typename Px<BD>::type;
     const int hs = j.hs, vs = j.vs;
     const int x = j.x0 >> hs, y = j.y0 >> vs, w = j.width >> hs, h = j.height >> vs;
@@ -693,6 +697,14 @@ __global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__rest
 }
 
 template <int BD>
+__global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__restrict__ jobs)
+{
+    __shared__ int prm[6];
+    const vvc355_cclm_job j = load_uniform(jobs + (blockIdx.x));
+    cclm_body<BD>(j, prm);
+}
+
+template <int BD>
 __device__ int lmcs_chroma_scale(const vvc355_lmcs_scale_job &j)
 {
     const uint8_t *luma = (const uint8_t *)j.luma;
@@ -791,6 +803,254 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
     const int *d_coeff = (const int *)call.linear(coeff, (size_t)n * sizeof(int), true, false);
     const vvc355_lmcs_scale_job *jd = call.upload(&dj, 1);
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((lmcs_scale_kernel<BD>), dim3(1), dim3(256), 0, call.stream(), jd, d_dst, d_coeff, n));
+    HIP_CHECK(hipGetLastError());
+}
+
+} // extern "C"
+
+// ================================================================================================ RECON stage driver
+// ff_vvc_reconstruct (vvc_intra.c:498-527) for a whole picture: one workgroup per CTU walks the CTU's command list in decoding
+// order (intra prediction reading what earlier blocks wrote, then the transform unit's residual), CTUs are released in wavefront
+// order.  See include/vvc_mi355.h (vvc355_recon_frame) for the command set and for what stays in the batched transform stage.
+//
+// Scheduling: workgroups take tickets (one atomic per workgroup) and process the CTUs that have commands in raster order of their
+// tickets, so every CTU a workgroup waits for belongs to a workgroup that is already running or done: no deadlock whatever the
+// dispatch order.  A CTU waits for its left, upper-left, upper and upper-right neighbours (those with commands; the others carry
+// only inter prediction + residuals finished by earlier launches).  Hand-off between workgroups: all stores of the CTU, every
+// wave's s_waitcnt vmcnt(0), workgroup barrier, then one lane's agent-scope release and the flag store; the consumer polls with
+// relaxed agent-scope loads, one agent-scope acquire, s_waitcnt, workgroup barrier, then plain loads (MI355X_MICROARCH.md,
+// "Valid forms").  Inside a workgroup a block's stores reach the later blocks' loads through the workgroup barrier (same CU, same L1).
+
+namespace vvc355 {
+
+struct ReconArea { int16_t x, y, w, h; };
+struct ReconLds {
+    uint16_t arr[4][kEdgeLen];
+    int scratch[16];
+    int prm[8];
+    ReconArea ras[2][1024];           // MAX_PARTS_IN_CTU (vvc_ctu.h:38) reconstructed areas per channel type, in decoding order
+    int num_ras[2];
+    int bc[8];
+};
+struct ReconCtx { int ctb_up, ctb_left, ctb_up_left, end_of_tiles_x; };
+
+// get_reconstructed_area (vvc_intra.c:574-589), one lane
+__device__ int recon_find_area(const ReconLds &L, int ch, int x, int y)
+{
+    for (int i = L.num_ras[ch] - 1; i >= 0; i--) {
+        const ReconArea a = L.ras[ch][i];
+        const int r = a.x + a.w, b = a.y + a.h;
+        if (a.x <= x && x < r && a.y <= y && y < b)
+            return i;
+        if (x >= r && y >= b)             // "it's too far away, no need check it"
+            break;
+    }
+    return -1;
+}
+// ff_vvc_get_top_available (vvc_intra.c:591-620), one lane
+__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_x0, int x, int y, int target, int c_idx)
+{
+    const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+    const int end_of_ctb_x = ((cu_x0 >> f.ctb_log2) + 1) << f.ctb_log2;
+    const int y0b = y & ((1 << (f.ctb_log2 - vs)) - 1);
+    const int max_x = min(f.width, end_of_ctb_x) >> hs;
+    if (!y0b) {
+        if (!cx.ctb_up)
+            return 0;
+        target = min(target, (cx.end_of_tiles_x >> hs) - x);
+        if (f.wpp)
+            target = min(target, (end_of_ctb_x >> hs) - x);
+        return target;
+    }
+    target = max(0, min(target, max_x - x));
+    int px = x, i;
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, px, y - 1)) >= 0) {
+        const int sz = min(target, L.ras[c_idx > 0][i].x + L.ras[c_idx > 0][i].w - px);
+        px += sz;
+        target -= sz;
+    }
+    return px - x;
+}
+// ff_vvc_get_left_available (vvc_intra.c:622-648), one lane
+__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_y0, int x, int y, int target, int c_idx)
+{
+    const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+    const int x0b = x & ((1 << (f.ctb_log2 - hs)) - 1);
+    const int end_of_ctb_y = ((cu_y0 >> f.ctb_log2) + 1) << f.ctb_log2;
+    const int max_y = min(f.height, end_of_ctb_y) >> vs;
+    if (!x0b && !cx.ctb_left)
+        return 0;
+    target = max(0, min(target, max_y - y));
+    if (!x0b)
+        return target;
+    int py = y, i;
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, x - 1, py)) >= 0) {
+        const int sz = min(target, L.ras[c_idx > 0][i].y + L.ras[c_idx > 0][i].h - py);
+        py += sz;
+        target -= sz;
+    }
+    return py - y;
+}
+// ff_vvc_wide_angle_mode_mapping (vvc_intra.c:693-714)
+__host__ __device__ inline int wide_angle_mode(int isp_split, int c_idx, int tb_w, int tb_h, int cb_w, int cb_h, int mode)
+{
+    const int nw = (!isp_split || c_idx) ? tb_w : cb_w, nh = (!isp_split || c_idx) ? tb_h : cb_h;
+    const int d = ilog2i(nw) - ilog2i(nh), wh_ratio = d < 0 ? -d : d;
+    const int mx = wh_ratio > 1 ? 8 + 2 * wh_ratio : 8, mn = wh_ratio > 1 ? 60 - 2 * wh_ratio : 60;
+    if (nw > nh && mode >= 2 && mode < mx)
+        return mode + 65;
+    if (nh > nw && mode <= 66 && mode > mn)
+        return mode - 67;
+    return mode;
+}
+
+static constexpr int kReconFlags = 16;        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done
+
+template <int BD>
+__global__ __launch_bounds__(256) void recon_wavefront_kernel(const vvc355_recon_frame *__restrict__ fp)
+{
+    __shared__ ReconLds L;
+    using px_t = typename Px<BD>::type;
+    const vvc355_recon_frame f = load_uniform(fp);
+    int *state = (int *)f.state;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        L.bc[0] = atomicAdd(&state[0], 1);
+    __syncthreads();
+    const int ticket = L.bc[0];
+    if (ticket >= f.n_work)
+        return;
+    const int rs = __builtin_amdgcn_readfirstlane(gld<int>((const int *)f.order + ticket));
+    const vvc355_recon_ctu *ctus = (const vvc355_recon_ctu *)f.ctus;
+    const vvc355_recon_ctu ctu = load_uniform(ctus + rs);
+    const int ncx = f.ctb_width, ry = rs / ncx, rx = rs - ry * ncx;
+    ReconCtx cx;
+    {
+        // ff_vvc_decode_neighbour (vvc_ctu.c:2468-2495)
+        const int16_t *slice_idx = (const int16_t *)f.slice_idx, *col_bd = (const int16_t *)f.ctb_to_col_bd, *row_bd = (const int16_t *)f.ctb_to_row_bd;
+        const int ctb = 1 << f.ctb_log2;
+        const bool left_tile = rx > 0 && gld<int16_t>(col_bd + rx) != gld<int16_t>(col_bd + rx - 1);
+        const bool upper_tile = ry > 0 && gld<int16_t>(row_bd + ry) != gld<int16_t>(row_bd + ry - 1);
+        const bool upper_slice = ry > 0 && gld<int16_t>(slice_idx + rs) != gld<int16_t>(slice_idx + rs - ncx);
+        cx.end_of_tiles_x = f.width;
+        if (gld<int16_t>(col_bd + rx) != gld<int16_t>(col_bd + rx + 1))
+            cx.end_of_tiles_x = min(rx * ctb + ctb, f.width);
+        cx.ctb_left = rx > 0 && !left_tile;
+        cx.ctb_up = ry > 0 && !upper_tile && !upper_slice;
+        cx.ctb_up_left = cx.ctb_left && cx.ctb_up;
+    }
+    // wait for the neighbours this CTU reads: left, upper-left, upper, upper-right (those that have commands)
+    if (tid == 0) {
+        const int dep[4] = { rx > 0 ? rs - 1 : -1, (rx > 0 && ry > 0) ? rs - ncx - 1 : -1, ry > 0 ? rs - ncx : -1, (ry > 0 && rx + 1 < ncx) ? rs - ncx + 1 : -1 };
+        for (int d = 0; d < 4; d++) {
+            if (dep[d] < 0 || gld<uint32_t>(&ctus[dep[d]].n_cmd) == 0)
+                continue;
+            while (__hip_atomic_load(&state[kReconFlags + dep[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        L.num_ras[0] = L.num_ras[1] = 0;
+    }
+    __syncthreads();
+
+    const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
+    const int ctb_mask = (1 << f.ctb_log2) - 1;
+    for (uint32_t k = 0; k < ctu.n_cmd; k++) {
+        const vvc355_recon_cmd c = load_uniform(cmds + k);
+        if (c.kind == VVC355_RECON_MARK) {
+            // add_reconstructed_area (vvc_intra.c:188-206)
+            if (tid == 0) {
+                const int ch = c.c_idx > 0, hs = ch ? f.hs : 0, vs = ch ? f.vs : 0, n = L.num_ras[ch];
+                if (n < 1024) {
+                    L.ras[ch][n] = ReconArea{ (int16_t)(c.x0 >> hs), (int16_t)(c.y0 >> vs), (int16_t)(c.w >> hs), (int16_t)(c.h >> vs) };
+                    L.num_ras[ch] = n + 1;
+                }
+            }
+            __syncthreads();
+        } else if (c.kind == VVC355_RECON_PRED) {
+            const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+            const int x = c.x0 >> hs, y = c.y0 >> vs, w = c.w >> hs, h = c.h >> vs;
+            if (tid == 0) {
+                L.bc[0] = recon_left_available(f, cx, L, c.cu_y0, x, y, 16384, c_idx);
+                L.bc[1] = recon_top_available(f, cx, L, c.cu_x0, x, y, 16384, c_idx);
+            }
+            __syncthreads();
+            vvc355_intra_job j = {};
+            j.plane = f.plane[c_idx];
+            j.stride = f.stride[c_idx];
+            j.x = (int16_t)x; j.y = (int16_t)y; j.w = (int16_t)w; j.h = (int16_t)h;
+            j.mode = (int16_t)wide_angle_mode(c.isp_split, c_idx, w, h, c.cb_width, c.cb_height, c.mode);
+            j.cb_width = c.cb_width; j.cb_height = c.cb_height;
+            j.left_avail = (int16_t)L.bc[0]; j.top_avail = (int16_t)L.bc[1];
+            j.c_idx = (uint8_t)c_idx; j.ref_idx = c_idx ? 0 : c.ref_idx;
+            j.is_mip = c.is_mip; j.mip_mode = c.mip_mode; j.mip_transposed = c.mip_transposed;
+            j.isp_split = c.isp_split; j.bdpcm_flag = c.bdpcm_flag;
+            {   // ff_vvc_set_neighbour_available (vvc_ctu.c:2497-2510), luma coordinates
+                const int x0b = c.x0 & ctb_mask, y0b = c.y0 & ctb_mask;
+                const bool cand_up = cx.ctb_up || y0b, cand_left = cx.ctb_left || x0b;
+                j.cand_up_left = (x0b || y0b) ? (cand_left && cand_up) : cx.ctb_up_left;
+            }
+            intra_pred_body<BD, 256>(j, L.arr, L.scratch, tid);
+            __syncthreads();
+        } else if (c.kind == VVC355_RECON_CCLM) {
+            if (tid == 0) {
+                L.bc[0] = recon_top_available(f, cx, L, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1);
+                L.bc[1] = recon_left_available(f, cx, L, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1);
+                L.bc[2] = recon_top_available(f, cx, L, c.cu_x0, c.x0, c.y0, 1, 0) != 0;
+                L.bc[3] = recon_left_available(f, cx, L, c.cu_y0, c.x0, c.y0, 1, 0) != 0;
+            }
+            __syncthreads();
+            vvc355_cclm_job j = {};
+            j.luma = f.plane[0]; j.cb = f.plane[1]; j.cr = f.plane[2];
+            j.luma_stride = f.stride[0]; j.cb_stride = f.stride[1]; j.cr_stride = f.stride[2];
+            j.x0 = c.x0; j.y0 = c.y0; j.width = c.w; j.height = c.h;
+            j.top_avail_c = (int16_t)L.bc[0]; j.left_avail_c = (int16_t)L.bc[1];
+            j.mode = (uint8_t)c.mode; j.hs = f.hs; j.vs = f.vs;
+            j.avail_t = (uint8_t)L.bc[2]; j.avail_l = (uint8_t)L.bc[3];
+            j.collocated = f.collocated;
+            j.ctu_boundary = (c.y0 & ctb_mask) == 0;
+            cclm_body<BD>(j, L.prm);
+            __syncthreads();
+        } else {
+            // RESID: itx.add_residual / add_residual_joint (vvcdsp_template.c:32,48) of the block the transform stage left in c.resid
+            const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w, n = w * c.h;
+            uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
+            const int *res = (const int *)c.resid;
+            const int lw = ilog2i(w);
+            for (int i = tid; i < n; i += 256) {
+                int r = gld<int>(res + i);
+                if (c.joint & 1)
+                    r = (r * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
+                const int yy = i >> lw, xx = i & (w - 1);
+                uint8_t *row = dst + row_off(yy, f.stride[c_idx]);
+                st_px<BD>(row, xx, clip_px<BD>(ld_px<BD>(row, xx) + r));
+            }
+            __syncthreads();
+        }
+    }
+    // publish: every wave's stores have left the CU, then one lane releases and raises the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+} // namespace vvc355
+
+extern "C" {
+
+size_t vvc355_recon_state_bytes(int n_ctus) { return sizeof(int) * (size_t)(vvc355::kReconFlags + (n_ctus > 0 ? n_ctus : 0)); }
+
+void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *frame_dev, const vvc355_recon_frame *frame_host)
+{
+    using namespace vvc355;
+    if (frame_host->n_work <= 0) return;
+    HIP_CHECK(hipMemsetAsync((void *)frame_host->state, 0, vvc355_recon_state_bytes(frame_host->ctb_width * frame_host->ctb_height), (hipStream_t)stream));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD>), dim3(frame_host->n_work), dim3(256), 0, (hipStream_t)stream, frame_dev));
     HIP_CHECK(hipGetLastError());
 }
 

@@ -59,6 +59,42 @@ __device__ __forceinline__ int inv_tx_out(int type, int n, int i, const int *in,
 // Scaling process for transform coefficients (vvc_intra.c:277-417) as a per-coefficient function: derive_qp's shift and
 // rectangular correction (:297-309), derive_scale (:311-338), derive_scale_m's up-sampling and DC override (:373-381),
 // scale_coeff (:391-397).  Shared by dequant_kernel and by the itx kernels' fused load stage.
+// derive_transform_type (vvc_intra.c:130-164): implicit / explicit MTS -> trh | trv << 4; flags = VVC355_TU_*
+__host__ __device__ inline int derive_tr_type(int flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h)
+{
+    const bool isp = flags & VVC355_TU_ISP, sbt = flags & VVC355_TU_SBT;
+    if (c_idx || (isp && lfnst_idx))
+        return 0;
+    bool implicit = false;
+    if (flags & VVC355_TU_MTS_ENABLED)
+        implicit = isp || (sbt && (w > h ? w : h) <= 32) ||
+                   (!(flags & VVC355_TU_EXPLICIT_MTS_INTRA) && (flags & VVC355_TU_INTRA) && !lfnst_idx && !(flags & VVC355_TU_MIP));
+    if (implicit) {
+        int trh, trv;
+        if (sbt) {
+            const bool hor = flags & VVC355_TU_SBT_HORIZONTAL, pos = flags & VVC355_TU_SBT_POS;
+            trh = (hor || pos) ? 1 : 2;
+            trv = (!hor || pos) ? 1 : 2;
+        } else {
+            trh = (w >= 4 && w <= 16) ? 1 : 0;
+            trv = (h >= 4 && h <= 16) ? 1 : 0;
+        }
+        return trh | (trv << 4);
+    }
+    // mts_idx -> (trh, trv): { DCT2, DST7, DCT8, DST7, DCT8 } / { DCT2, DST7, DST7, DCT8, DCT8 }
+    const int trh = mts_idx == 0 ? 0 : (mts_idx & 1) ? 1 : 2, trv = mts_idx == 0 ? 0 : mts_idx <= 2 ? 1 : 2;
+    return trh | (trv << 4);
+}
+// a job that asks for it gets its transform types from the rule above instead of from its trh / trv fields
+__device__ __forceinline__ void resolve_type(vvc355_itx_job &job)
+{
+    if (job.mts_flags & VVC355_ITX_DERIVE_TYPE) {
+        const int t = derive_tr_type(job.tu_flags, job.mts_idx, job.lfnst_idx, job.c_idx, 1 << job.log2_w, 1 << job.log2_h);
+        job.trh = (uint8_t)(t & 15);
+        job.trv = (uint8_t)(t >> 4);
+    }
+}
+
 struct Dequant {
     int on, scale, bd_shift, bd_offset, range, lw, lh, lm, dc;
     const uint8_t *sm;
@@ -345,7 +381,8 @@ __global__ __launch_bounds__(256) void itx_kernel(const vvc355_itx_job *__restri
     const int ji = blockIdx.x * TBS + sub;
     if (ji >= n_jobs)
         return;                                      // whole groups leave together
-    const vvc355_itx_job job = jobs[ji];
+    vvc355_itx_job job = jobs[ji];
+    resolve_type(job);
     if (job.log2_w + job.log2_h > __builtin_ctz(CAP))
         return;                                      // larger than this launch's size class: contract violation, skipped
     itx_generic_block<BD, NT, CAP>(job, buf_all[sub], tmp_all[sub], cos_lds, tid);
@@ -431,7 +468,8 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
     const int wg = xcd_chunked(blockIdx.x, gridDim.x);
     const int ji = wg * TBS + sub;
     const bool valid = ji < n_jobs;
-    const vvc355_itx_job job = jobs[valid ? ji : n_jobs - 1];
+    vvc355_itx_job job = jobs[valid ? ji : n_jobs - 1];
+    resolve_type(job);
     const int nzw = job.nzw, nzh = job.nzh, range = job.range, bd = job.bd ? job.bd : BD;
     const int trh = job.trh, trv = job.trv;
     const int sh_final = 5 + range - bd;
@@ -492,7 +530,8 @@ __global__ __launch_bounds__(256) void itx_shape_kernel(const vvc355_itx_job *__
             const int jb = wg * TBS + b;
             if (jb >= n_jobs)
                 break;
-            const vvc355_itx_job jg = jobs[jb];
+            vvc355_itx_job jg = jobs[jb];
+            resolve_type(jg);
             if (jg.log2_w + jg.log2_h <= LW + LH)
                 itx_generic_block<BD, 256, CAP>(jg, gbuf, gtmp, cos_lds, threadIdx.x);
             __syncthreads();
@@ -680,6 +719,65 @@ __global__ __launch_bounds__(64) void lfnst_kernel(int *v, const int *u, int nz,
     v[j] = clip_intp2(((int)t + 64) >> 7, range);
 }
 
+// dequant (when asked) + ilfnst_transform (vvc_intra.c:65-127) of one transform block per wave, in place: the scaling process over
+// the whole scan window first (what the reference's dequant leaves, :400-417), then the first 8 / 16 levels in 4x4 diagonal scan
+// order through ff_vvc_inv_lfnst_1d, scattered into the top-left 4x4 or the 8x8 L-shape (48 outputs), transposed for modes > 34
+__global__ __launch_bounds__(256) void lfnst_batch_kernel(const vvc355_lfnst_job *__restrict__ jobs, int n_jobs)
+{
+    __shared__ int u_all[4][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ji = blockIdx.x * 4 + wave;
+    if (ji >= n_jobs)
+        return;
+    const vvc355_lfnst_job job = jobs[ji];
+    int *coeffs = (int *)job.coeffs;
+    const int lw = job.log2_w, w = 1 << lw, h = 1 << job.log2_h;
+    if (job.dequant) {
+        Dequant dq;
+        dq.setup(1, lw, job.log2_h, job.qp, 0, job.dep_quant, job.bit_depth, job.range, (const uint8_t *)job.scale_matrix, job.log2_matrix_size, job.dc);
+        const int rw = job.max_x + 1, n = rw * (job.max_y + 1);
+        for (int i = lane; i < n; i += 64) {
+            const int y = i / rw, x = i - y * rw;
+            const int c = gld<int>(coeffs + (y << lw) + x);
+            if (c)
+                gst<int>(coeffs + (y << lw) + x, dq.apply(c, x, y));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the gather below reads what other lanes of this wave stored
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const bool big = w >= 8 && h >= 8;
+    const int n_out = big ? 48 : 16;
+    const int nz = ((w == 8 && h == 8) || (w == 4 && h == 4)) ? 8 : 16;
+    // 6.5.2 up-right diagonal scan of a 4x4 block (ff_vvc_diag_scan_x / _y [2][2]), packed one nibble per position
+    const unsigned long long sx = 0x3323213210210100ull, sy = 0x3231230123012010ull;
+    if (lane < 16)
+        u_all[wave][lane] = lane < nz ? gld<int>(coeffs + w * (int)((sy >> (4 * lane)) & 15) + (int)((sx >> (4 * lane)) & 15)) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n_out) {
+        const int mode = job.pred_mode_intra;
+        const int set = mode < 0 ? 1 : d_tab_lfnst_tr_set_index[mode];
+        const int8_t *m = big ? d_tab_lfnst_8x8 + (set * 2 + job.lfnst_idx - 1) * 16 * 48 : d_tab_lfnst_4x4 + (set * 2 + job.lfnst_idx - 1) * 16 * 16;
+        unsigned t = 0;
+        for (int i = 0; i < nz; i++)
+            t += (unsigned)u_all[wave][i] * (unsigned)(int)m[i * n_out + lane];
+        const int v = clip_intp2(((int)t + 64) >> 7, job.range);
+        int x, y;
+        const int j = lane;
+        if (mode > 34) {            // transposed placement (:86-110)
+            if (!big)        { y = j & 3; x = j >> 2; }
+            else if (j < 32) { y = j & 7; x = j >> 3; }
+            else             { y = (j - 32) & 3; x = 4 + ((j - 32) >> 2); }
+        } else {                    // row by row: 8 (4) values in rows 0..3, 4 in rows 4..7 (:111-120)
+            if (!big)        { y = j >> 2; x = j & 3; }
+            else if (j < 32) { y = j >> 3; x = j & 7; }
+            else             { y = 4 + ((j - 32) >> 2); x = (j - 32) & 3; }
+        }
+        gst<int>(coeffs + y * w + x, v);
+    }
+}
+
 static bool itx_entry_exists(int trh, int trv, int lw, int lh)
 {
     if (lw < 0 || lh < 0 || lw > 6 || lh > 6 || trh < 0 || trh > 2 || trv < 0 || trv > 2 || (lw == 0 && lh == 0))
@@ -802,6 +900,32 @@ void vvc355_inv_lfnst_1d(int *v, const int *u, int no_zero_size, int n_tr_s, int
     const int *du = (const int *)call.linear(u, (size_t)no_zero_size * sizeof(int), true, false);
     hipLaunchKernelGGL(lfnst_kernel, dim3(1), dim3(64), 0, call.stream(), dv, du, no_zero_size, n_tr_s, set, lfnst_idx, log2_transform_range);
     HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_lfnst_batch(void *stream, const vvc355_lfnst_job *jobs_dev, int n_jobs)
+{
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(lfnst_batch_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    HIP_CHECK(hipGetLastError());
+}
+
+int vvc355_ilfnst_transform(int *coeffs, int w, int h, int pred_mode_intra, int lfnst_idx, int log2_transform_range)
+{
+    SlotCall call;
+    vvc355_lfnst_job job = {};
+    job.coeffs = (uint64_t)call.linear(coeffs, (size_t)w * h * sizeof(int), true, true);
+    int lw = 0, lh = 0;
+    while ((1 << lw) < w) lw++;
+    while ((1 << lh) < h) lh++;
+    job.log2_w = (uint8_t)lw; job.log2_h = (uint8_t)lh; job.range = (uint8_t)log2_transform_range;
+    job.pred_mode_intra = (int8_t)pred_mode_intra; job.lfnst_idx = (uint8_t)lfnst_idx;
+    vvc355_lfnst_batch(call.stream(), call.upload(&job, 1), 1);
+    return (w >= 8 && h >= 8) ? 8 : 4;
+}
+
+int vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h)
+{
+    return derive_tr_type(tu_flags, mts_idx, lfnst_idx, c_idx, w, h);
 }
 
 static void slot_residual(int bd, int mode, uint8_t *dst, int *res, int width, int height, ptrdiff_t stride, int c_sign, int shift)

@@ -21,6 +21,10 @@ void *vvc355_malloc(size_t bytes)
 void vvc355_free(void *dev) { HIP_CHECK(hipFree(dev)); }
 void vvc355_upload(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice)); }
 void vvc355_download(void *host, const void *dev, size_t bytes) { HIP_CHECK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost)); }
+void vvc355_copy_async(void *stream, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+}
 void *vvc355_stream_create(void)
 {
     hipStream_t s;

@@ -37,6 +37,7 @@ void *vvc355_malloc(size_t bytes);
 void  vvc355_free(void *dev);
 void  vvc355_upload(void *dev, const void *host, size_t bytes);
 void  vvc355_download(void *host, const void *dev, size_t bytes);
+void  vvc355_copy_async(void *stream, void *dst_dev, const void *src_dev, size_t bytes);   /* device to device, stream-ordered */
 void *vvc355_stream_create(void);
 void  vvc355_stream_destroy(void *stream);
 void  vvc355_stream_sync(void *stream);          /* NULL = the default stream */
@@ -239,6 +240,7 @@ int  vvc355_lf_ladf_level(int bd, int dir, const uint8_t *pix, ptrdiff_t stride)
 /* ------------------------------------------------------------------ inverse transform + residual (itx.hip) */
 
 enum { VVC355_DCT2 = 0, VVC355_DST7 = 1, VVC355_DCT8 = 2 };     /* enum TxType, vvcdsp.h:30 */
+enum { VVC355_ITX_DERIVE_TYPE = 1 };
 
 /* One transform block.  coeffs: DEVICE int32[w*h], row-major (stride w), transformed in place when store_coeffs != 0.
  * dst != 0 additionally adds the residual to the w x h pixel rectangle at dst (itx + add_residual fused, what
@@ -256,7 +258,10 @@ typedef struct vvc355_itx_job {
     uint8_t  dq_flags, dq_qp, log2_matrix_size;
     uint64_t scale_matrix;
     int16_t  dc;
-    uint8_t  pad_[6];
+    /* derive_transform_type on the device (vvc_intra.c:130-164): with VVC355_ITX_DERIVE_TYPE in mts_flags, trh / trv above are ignored
+     * and derived from tu_flags (VVC355_TU_*), mts_idx, lfnst_idx and c_idx */
+    uint8_t  mts_flags, tu_flags, mts_idx, lfnst_idx, c_idx;
+    uint8_t  pad_;
 } vvc355_itx_job;
 
 /* max_log2_area = max over the batch of log2_w + log2_h; it selects the lanes-per-block mapping (<= 6: a wave per block) */
@@ -624,6 +629,83 @@ typedef struct vvc355_alf_frame {
 
 size_t vvc355_alf_frame_work_bytes(int n_ctbs);
 void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev);
+
+/* ------------------------------------------------------------------ LFNST and transform-type selection on device (itx.hip) */
+
+/*
+ * The two steps the reference does in host C between dequant and the table's inverse transform, itransform (vvc_intra.c:431-476):
+ *   ilfnst_transform (:65-127)       gather by the 4x4 diagonal scan, ff_vvc_inv_lfnst_1d, scatter into the top-left 4x4 / 8x8 L-shape
+ *                                    (transposed for pred_mode_intra > 34), max_scan := 3 or 7
+ *   derive_transform_type (:130-164) implicit / explicit MTS -> (trh, trv)
+ * Flattened: pred_mode_intra = what derive_ilfnst_pred_mode_intra (:34-62) returns; tu_flags = VVC355_TU_* of the coding unit and SPS.
+ */
+enum { VVC355_TU_MTS_ENABLED = 1, VVC355_TU_EXPLICIT_MTS_INTRA = 2, VVC355_TU_ISP = 4, VVC355_TU_SBT = 8, VVC355_TU_SBT_HORIZONTAL = 16,
+       VVC355_TU_SBT_POS = 32, VVC355_TU_INTRA = 64, VVC355_TU_MIP = 128 };
+
+/* One transform block that carries LFNST: the scaling process (same fields as vvc355_dequant_job, window min 0 .. max) and then
+ * ilfnst_transform, in place on coeffs.  The inverse transform that follows takes nzw = nzh = 4 (4-wide / 4-high blocks) or 8. */
+typedef struct vvc355_lfnst_job {
+    uint64_t coeffs;
+    uint64_t scale_matrix;
+    uint8_t  log2_w, log2_h, max_x, max_y;
+    uint8_t  qp, dequant, dep_quant, bit_depth, range, log2_matrix_size;   /* dequant = 0: coefficients are already scaled */
+    int16_t  dc;
+    int8_t   pred_mode_intra;
+    uint8_t  lfnst_idx;      /* 1 or 2 */
+    uint8_t  pad_[2];
+} vvc355_lfnst_job;
+void vvc355_lfnst_batch(void *stream, const vvc355_lfnst_job *jobs_dev, int n_jobs);
+/* synchronous forms (host pointers) */
+int  vvc355_ilfnst_transform(int *coeffs, int w, int h, int pred_mode_intra, int lfnst_idx, int log2_transform_range);
+/* returns trh | trv << 4; the batched transform entries apply the same rule on the device when a job sets VVC355_ITX_DERIVE_TYPE */
+int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h);
+
+/* ------------------------------------------------------------------ RECON stage driver: in-order CTU interpreter + wavefront (recon.hip) */
+
+/*
+ * ff_vvc_reconstruct (vvc_intra.c:498-527) for a whole picture: every CTU's coding units are walked in decoding order — intra
+ * prediction (predict_intra :245-274 -> intra_pred / intra_cclm_pred) reading neighbours that earlier blocks have written, then
+ * the residual of the transform unit — and CTUs are released in wavefront order: a CTU starts when its left, upper-left, upper and
+ * upper-right neighbours are done (the reference's scheduler waits for left + upper-right, vvc_thread.c:156-184, whose own
+ * dependencies cover the other two).  The walk is a command list per CTU, one command per reference call in the reference's order:
+ *   MARK   add_reconstructed_area(lc, c_idx > 0, x0, y0, w, h)                                   (luma coordinates, :188-206)
+ *   PRED   intra.intra_pred(lc, x0, y0, w, h, c_idx)                                             (luma coordinates, like the slot)
+ *   CCLM   intra.intra_cclm_pred(lc, x0, y0, w, h)
+ *   RESID  itx.add_residual / add_residual_joint of transform block (tb->x0, tb->y0 luma coordinates; w, h = tb_width, tb_height)
+ * Neighbour availability is derived on the device from the running list of reconstructed areas exactly as
+ * ff_vvc_get_top_available / _left_available do (:574-648), ctb_up / ctb_left flags from the slice and tile tables
+ * (ff_vvc_decode_neighbour, vvc_ctu.c:2468), the wide-angle mapping (:693) from the command's mode.
+ * Residuals are the outputs of the batched transform stage (vvc355_itx_*_batch with store_coeffs): the inverse transform does
+ * not depend on neighbours, so only prediction + add is serialised.  Transform blocks of coding units that are not intra-coded
+ * are added by the batched stage itself (dst != 0) before this pass; their CTUs need no commands.
+ */
+enum { VVC355_RECON_MARK = 0, VVC355_RECON_PRED = 1, VVC355_RECON_CCLM = 2, VVC355_RECON_RESID = 3 };
+typedef struct vvc355_recon_cmd {
+    uint64_t resid;            /* RESID: DEVICE int32[w * h] */
+    int16_t  x0, y0, w, h;
+    int16_t  cu_x0, cu_y0;     /* lc->cu->x0, y0: end_of_ctb_x / _y of the availability process */
+    int16_t  cb_width, cb_height;
+    int8_t   mode;             /* cu->intra_pred_mode_y / _c as parsed (before the wide-angle mapping); CCLM: 81, 82, 83 */
+    uint8_t  kind, c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag;
+    uint8_t  joint;            /* RESID: bit 0 = add_residual_joint, bit 1 = c_sign negative, bit 2 = shift */
+    uint8_t  pad_[6];
+} vvc355_recon_cmd;
+typedef struct vvc355_recon_ctu { uint32_t first_cmd, n_cmd; } vvc355_recon_ctu;
+typedef struct vvc355_recon_frame {
+    uint64_t plane[3];            /* component planes, predicted / reconstructed in place */
+    uint64_t cmds, ctus;          /* vvc355_recon_cmd[], vvc355_recon_ctu per CTU (raster order; n_cmd = 0: nothing to do) */
+    uint64_t order;               /* int32 raster indices of the CTUs that have commands, ascending; n_work entries */
+    uint64_t state;               /* DEVICE scratch of vvc355_recon_state_bytes(): ticket counter + per-CTU done flags */
+    uint64_t slice_idx, ctb_to_col_bd, ctb_to_row_bd;    /* int16 per CTB / per CTB column (+1) / per CTB row (+1) */
+    int32_t  stride[3];           /* bytes */
+    int32_t  width, height, ctb_width, ctb_height, n_work;
+    uint8_t  ctb_log2, hs, vs;
+    uint8_t  wpp;                 /* sps_entropy_coding_sync_enabled_flag */
+    uint8_t  collocated;          /* sps_chroma_vertical_collocated_flag */
+    uint8_t  pad_[3];
+} vvc355_recon_frame;
+size_t vvc355_recon_state_bytes(int n_ctus);
+void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *frame_dev, const vvc355_recon_frame *frame_host);
 
 #ifdef __cplusplus
 }

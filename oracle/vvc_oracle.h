@@ -286,6 +286,33 @@ void orc_pred_angular_h(int bd, uint8_t *src, const uint8_t *top, const uint8_t 
 void orc_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *left, int w, int h, ptrdiff_t stride,
     int mode_id, int is_transpose);
 
+/* ---- transform-side helpers between dequant and the inverse transform (orc_recon.c) ---- */
+enum { ORC_TU_MTS_ENABLED = 1, ORC_TU_EXPLICIT_MTS_INTRA = 2, ORC_TU_ISP = 4, ORC_TU_SBT = 8, ORC_TU_SBT_HORIZONTAL = 16, ORC_TU_SBT_POS = 32,
+       ORC_TU_INTRA = 64, ORC_TU_MIP = 128 };
+int  orc_ilfnst_transform(int *coeffs, int w, int h, int pred_mode_intra, int lfnst_idx, int log2_transform_range);
+int  orc_derive_transform_type(int flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h);
+
+/* ---- RECON of a picture from per-CTU command lists (orc_recon.c, "ff_vvc_reconstruct"); layouts as in include/vvc_mi355.h ---- */
+enum { ORC_RECON_MARK = 0, ORC_RECON_PRED = 1, ORC_RECON_CCLM = 2, ORC_RECON_RESID = 3 };
+typedef struct orc_recon_cmd {
+    uint64_t resid;
+    int16_t  x0, y0, w, h;
+    int16_t  cu_x0, cu_y0, cb_width, cb_height;
+    int8_t   mode;
+    uint8_t  kind, c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag, joint;
+    uint8_t  pad_[6];
+} orc_recon_cmd;
+typedef struct orc_recon_ctu { uint32_t first_cmd, n_cmd; } orc_recon_ctu;
+typedef struct orc_recon_frame {
+    uint64_t plane[3];
+    uint64_t cmds, ctus, order, state;
+    uint64_t slice_idx, ctb_to_col_bd, ctb_to_row_bd;
+    int32_t  stride[3];
+    int32_t  width, height, ctb_width, ctb_height, n_work;
+    uint8_t  ctb_log2, hs, vs, wpp, collocated, pad_[3];
+} orc_recon_frame;
+void orc_recon_frame_pass(int bd, const orc_recon_frame *f);
+
 #ifdef __cplusplus
 }
 #endif

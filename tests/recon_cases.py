@@ -1,0 +1,128 @@
+"""Synthetic RECON workloads (vvc355_recon_frame_pass / orc_recon_frame_pass): a random partition of every CTU into coding units
+(tests/bs_cases._split), intra or not, flattened into the per-CTU command lists the RECON stage driver consumes — one command per
+reference call, in the order ff_vvc_reconstruct / reconstruct / predict_intra / itransform make them (vvc_intra.c:245-274,
+:431-527).  Used by the GPU parity test and by bench.py's intra stage."""
+import numpy as np
+
+from ffvvc_amd import abi
+from bs_cases import _split
+
+CMD = np.dtype(abi.ReconCmd, align=True)
+CTU = np.dtype(abi.ReconCtu, align=True)
+
+
+class ReconWork:
+    """cmds / ctus / order as numpy arrays with the C layouts; `resid_len` int32 entries of residual storage are addressed by
+    cmds["resid"] as ELEMENT offsets until `bind(base_address)` turns them into addresses."""
+
+    def __init__(self, rng, width, height, ctb_log2=7, hs=1, vs=1, intra_frac=1.0, intra_ctu=None, cclm_frac=0.2, coded_p=0.7,
+                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True):
+        self.width, self.height, self.ctb_log2, self.hs, self.vs = width, height, ctb_log2, hs, vs
+        ctb = 1 << ctb_log2
+        self.ncx, self.ncy = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
+        n_ctb = self.ncx * self.ncy
+        cuts = np.sort(rng.integers(1, max(2, n_ctb), size=n_slices - 1)) if n_slices > 1 else []
+        self.slice_idx = np.searchsorted(cuts, np.arange(n_ctb), side="right").astype(np.int16)
+        if tiles and self.ncx > 2 and self.ncy > 1:
+            cx, cy = int(rng.integers(1, self.ncx)), int(rng.integers(1, self.ncy))
+            self.col_bd = np.array([0 if x < cx else cx for x in range(self.ncx)] + [self.ncx], np.int16)
+            self.row_bd = np.array([0 if y < cy else cy for y in range(self.ncy)] + [self.ncy], np.int16)
+        else:
+            self.col_bd = np.array([0] * self.ncx + [self.ncx], np.int16)
+            self.row_bd = np.array([0] * self.ncy + [self.ncy], np.int16)
+        cmds, ctus = [], np.zeros(n_ctb, CTU)
+        self.resid_len = 0
+        self.tbs = []                     # (c_idx, x0, y0 luma, w, h component samples, element offset): what the transform stage must fill
+        for rs in range(n_ctb):
+            rx, ry = rs % self.ncx, rs // self.ncx
+            first = len(cmds)
+            ctu_intra = intra_frac if intra_ctu is None else (1.0 if intra_ctu[rs] else 0.0)
+            leaves = []
+            _split(rng, rx * ctb, ry * ctb, ctb, ctb, width, height, min_cu, leaves, *split)
+            any_intra = False
+            cu_cmds = []
+            for (x, y, w, h) in leaves:
+                if rng.random() >= ctu_intra:
+                    # not intra-coded: prediction and residual come from the batched stages, the walk only records the area
+                    cu_cmds.append(self._cmd(abi.RECON_MARK, 0, x, y, w, h, x, y, w, h))
+                    cu_cmds.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, x, y, w, h))
+                    continue
+                any_intra = True
+                self._intra_cu(rng, cu_cmds, x, y, w, h, ctb, cclm_frac, coded_p, tools)
+            if any_intra:
+                cmds += cu_cmds
+                ctus[rs]["first_cmd"], ctus[rs]["n_cmd"] = first, len(cu_cmds)
+        self.cmds = np.array(cmds, CMD) if cmds else np.zeros(0, CMD)
+        self.ctus = ctus
+        self.order = np.nonzero(ctus["n_cmd"])[0].astype(np.int32)
+
+    @staticmethod
+    def _cmd(kind, c_idx, x0, y0, w, h, cu_x, cu_y, cb_w, cb_h, resid=0, mode=0, ref_idx=0, is_mip=0, mip_mode=0, mip_transposed=0,
+             isp_split=0, bdpcm_flag=0, joint=0):
+        # a tuple in the field order of vvc355_recon_cmd (plain tuples: a frame has hundreds of thousands of commands)
+        return (resid, x0, y0, w, h, cu_x, cu_y, cb_w, cb_h, mode, kind, c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split,
+                bdpcm_flag, joint, (0,) * 6)
+
+    def _resid(self, c_idx, x0, y0, w, h):
+        off = self.resid_len
+        self.resid_len += w * h
+        self.tbs.append((c_idx, x0, y0, w, h, off))
+        return off
+
+    def _intra_cu(self, rng, out, x, y, w, h, ctb, cclm_frac, coded_p, tools):
+        hs, vs = self.hs, self.vs
+        cu = (x, y, w, h)
+        mode = int(rng.choice([0, 1, 18, 50] + list(range(2, 67))))
+        y0b = y & (ctb - 1)
+        isp = tools and w >= 8 and h >= 16 and rng.random() < 0.15
+        is_mip = tools and not isp and w <= 64 and h <= 64 and rng.random() < 0.1
+        ref_idx = int(rng.choice([1, 2])) if (tools and y0b and not is_mip and not isp and mode != 0 and rng.random() < 0.15) else 0
+        bdpcm = int(tools and mode in (18, 50) and not isp and not is_mip and w <= 32 and h <= 32 and rng.random() < 0.3)
+        kw = dict(mode=0 if is_mip else mode, ref_idx=ref_idx, is_mip=int(is_mip), isp_split=int(isp), bdpcm_flag=bdpcm)
+        if is_mip:
+            size_id = 0 if (w == 4 and h == 4) else 1 if (w == 4 or h == 4 or (w == 8 and h == 8)) else 2
+            kw["mip_mode"], kw["mip_transposed"] = int(rng.integers(0, (16, 8, 6)[size_id])), int(rng.integers(0, 2))
+        # luma (ch_type 0): one transform unit, or ISP's horizontal sub-partitions — predict, record, add the residual
+        parts = [(x, y, w, h)]
+        if isp:
+            k = 4 if h >= 32 else 2
+            parts = [(x, y + i * h // k, w, h // k) for i in range(k)]
+        for (px, py, pw, ph) in parts:
+            out.append(self._cmd(abi.RECON_PRED, 0, px, py, pw, ph, *cu, **kw))
+            out.append(self._cmd(abi.RECON_MARK, 0, px, py, pw, ph, *cu))
+            if rng.random() < coded_p:
+                out.append(self._cmd(abi.RECON_RESID, 0, px, py, pw, ph, *cu, resid=self._resid(0, px, py, pw, ph)))
+        # chroma (ch_type 1): both components predicted over the coding unit, then their residuals (joint Cb-Cr now and then)
+        cw, chh = w >> hs, h >> vs
+        if tools and rng.random() < cclm_frac:
+            out.append(self._cmd(abi.RECON_CCLM, 1, x, y, w, h, *cu, mode=int(rng.choice([81, 82, 83]))))
+        else:
+            cmode = int(rng.choice([0, 1, 18, 50, mode]))
+            for c in (1, 2):
+                out.append(self._cmd(abi.RECON_PRED, c, x, y, w, h, *cu, mode=cmode, bdpcm_flag=0))
+        out.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, *cu))
+        joint = tools and rng.random() < 0.15
+        for c in (1, 2):
+            if rng.random() < coded_p:
+                out.append(self._cmd(abi.RECON_RESID, c, x, y, cw, chh, *cu, resid=self._resid(c, x, y, cw, chh)))
+                if joint and c == 1:
+                    # add_residual_for_joint_coding_chroma (:166-186): the same residual goes to the other component, signed / halved
+                    out.append(self._cmd(abi.RECON_RESID, 2, x, y, cw, chh, *cu, resid=out[-1][0], joint=1 | (2 * int(rng.integers(0, 2))) | (4 * int(rng.integers(0, 2)))))
+                    break
+
+    def bind(self, base):
+        """Command array with residual element offsets turned into addresses at `base` (int32 storage)."""
+        c = self.cmds.copy()
+        is_res = c["kind"] == abi.RECON_RESID
+        c["resid"][is_res] = base + c["resid"][is_res] * 4
+        return c
+
+    def frame(self, planes, strides, cmds_ptr, ctus_ptr, order_ptr, state_ptr, slice_ptr, col_ptr, row_ptr, wpp=0, collocated=0):
+        f = abi.ReconFrame()
+        for c in range(3):
+            f.plane[c], f.stride[c] = planes[c], strides[c]
+        f.cmds, f.ctus, f.order, f.state = cmds_ptr, ctus_ptr, order_ptr, state_ptr
+        f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = slice_ptr, col_ptr, row_ptr
+        f.width, f.height, f.ctb_width, f.ctb_height, f.n_work = self.width, self.height, self.ncx, self.ncy, len(self.order)
+        f.ctb_log2, f.hs, f.vs, f.wpp, f.collocated = self.ctb_log2, self.hs, self.vs, wpp, collocated
+        return f

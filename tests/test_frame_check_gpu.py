@@ -25,7 +25,7 @@ def test_bench_frame_against_oracle(width, height, bd, noise):
     for name, r in rep["stages"].items():
         assert r.get("mismatching", 0) == 0, (name, r)
     checked = [name for name, r in rep["stages"].items() if r["checked"]]
-    assert {"inter_pred_luma_dmvr_bdof", "inter_pred_chroma", "dequant_itx_add_residual", "lmcs_inverse_luma", "deblock_bs",
+    assert {"inter_pred_luma_dmvr_bdof", "inter_pred_chroma", "dequant_itx_add_residual", "intra_tb_dequant_lfnst_itx", "intra_recon_wavefront", "lmcs_inverse_luma", "deblock_bs",
             "deblock_vertical", "deblock_horizontal", "sao", "alf"} <= set(checked)
     if not noise:
         # picture-like content must exercise the tools' decisions both ways and make deblocking actually filter

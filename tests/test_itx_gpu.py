@@ -1,7 +1,11 @@
 """GPU parity: inverse transform / LFNST / residual slots through the C ABI vs the CPU oracle, bit-exact.
 Mirrors tests/checkasm/vvc_itx.c:25-36,48-51,58-93: every (trh, trv, w, h) the table holds, random nzw/nzh inside the
 zero-out limits (32 for DCT-2, 16 for DST-7/DCT-8), coefficients clipped to log2_transform_range, zeros elsewhere."""
+import ctypes
+
 import numpy as np
+
+from ffvvc_amd import abi
 import pytest
 
 from conftest import P, rand_pixels
@@ -231,3 +235,85 @@ def test_dequant_batch(dev, orc):
     dev.vvc355_stream_sync(None)
     for (d_c, _), a in zip(bufs, want):
         assert np.array_equal(d_c.to_host(np.int32, a.shape), a)
+
+
+def test_ilfnst_transform_and_batch(dev, orc):
+    """ilfnst_transform (vvc_intra.c:65-127) on the device: every block shape class (4x4, 8x8, 4xN / Nx4, >= 8x8 L-shape), modes on
+    both sides of the transpose threshold, both lfnst_idx — synchronous entry and the batched kernel fused with the scaling process."""
+    from ffvvc_amd import batch
+    rng = np.random.default_rng(0x5EED0F10)
+    orc.orc_ilfnst_transform.restype = ctypes.c_int
+    orc.orc_ilfnst_transform.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+    shapes = [(4, 4), (8, 8), (4, 16), (16, 4), (8, 16), (16, 16), (32, 8), (64, 64), (4, 8), (8, 4)]
+    jobs, host, want = [], [], []
+    for it in range(200):
+        w, h = shapes[it % len(shapes)]
+        mode = int(rng.integers(-14, 81))
+        idx = int(rng.integers(1, 3))
+        co = np.zeros((h, w), np.int32)
+        co[:min(h, 4), :min(w, 4)] = rng.integers(-(1 << 11), 1 << 11, size=(min(h, 4), min(w, 4)))
+        a, b = co.copy(), co.copy()
+        na = orc.orc_ilfnst_transform(a.ctypes.data, w, h, mode, idx, 15)
+        nb = dev.vvc355_ilfnst_transform(b.ctypes.data, w, h, mode, idx, 15)
+        assert na == nb and np.array_equal(a, b), (w, h, mode, idx)
+        # batched: quantised levels in, dequant + LFNST on the device
+        lv = np.zeros((h, w), np.int32)
+        lv[:min(h, 4), :min(w, 4)] = rng.integers(-40, 41, size=(min(h, 4), min(w, 4)))
+        qp, dep = int(rng.integers(20, 40)), int(rng.integers(0, 2))
+        e = lv.copy()
+        lw, lh = int(np.log2(w)), int(np.log2(h))
+        orc.orc_dequant(e.ctypes.data, lw, lh, 0, 0, min(w, 4) - 1, min(h, 4) - 1, qp, 0, dep, 10, 15, None, 1, -1)
+        orc.orc_ilfnst_transform(e.ctypes.data, w, h, mode, idx, 15)
+        j = abi.LfnstJob()
+        j.log2_w, j.log2_h, j.max_x, j.max_y, j.qp, j.dequant, j.dep_quant, j.bit_depth, j.range = lw, lh, min(w, 4) - 1, min(h, 4) - 1, qp, 1, dep, 10, 15
+        j.log2_matrix_size, j.dc, j.pred_mode_intra, j.lfnst_idx = 1, -1, mode, idx
+        jobs.append(j); host.append(lv); want.append(e)
+    d_co = [batch.DeviceBuffer.from_host(c) for c in host]
+    arr = (abi.LfnstJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        j.coeffs = d_co[i].ptr
+        arr[i] = j
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_lfnst_batch(None, d_jobs.ptr, len(jobs))
+    dev.vvc355_stream_sync(None)
+    for i in range(len(jobs)):
+        assert np.array_equal(d_co[i].to_host(np.int32, want[i].shape), want[i]), i
+
+
+def test_derive_transform_type_on_device(dev, orc):
+    """derive_transform_type (vvc_intra.c:130-164): jobs that ask the device to derive (trh, trv) from the coding unit's flags must
+    transform exactly like jobs given the oracle's derivation; also the host-callable form over the whole flag space."""
+    from ffvvc_amd import batch
+    rng = np.random.default_rng(0x5EED0F20)
+    orc.orc_derive_transform_type.restype = ctypes.c_int
+    orc.orc_derive_transform_type.argtypes = [ctypes.c_int] * 6
+    for flags in range(256):
+        for mts in range(5):
+            for (lf, c, w, h) in ((0, 0, 16, 8), (1, 0, 4, 32), (0, 1, 8, 8), (0, 0, 64, 16), (2, 0, 32, 32)):
+                assert orc.orc_derive_transform_type(flags, mts, lf, c, w, h) == dev.vvc355_derive_transform_type(flags, mts, lf, c, w, h)
+    n = 400
+    arr = (abi.ItxJob * n)()
+    bufs, want = [], []
+    for i in range(n):
+        lw, lh = int(rng.integers(2, 6)), int(rng.integers(2, 6))
+        w, h = 1 << lw, 1 << lh
+        flags, mts, lf, c = int(rng.integers(0, 256)), int(rng.integers(0, 5)), int(rng.integers(0, 3)), int(rng.integers(0, 4) == 0)
+        t = orc.orc_derive_transform_type(flags, mts, lf, c, w, h)
+        trh, trv = t & 15, t >> 4
+        nzw, nzh = int(rng.integers(1, min(w, 16) + 1)), int(rng.integers(1, min(h, 16) + 1))
+        co = np.zeros((h, w), np.int32)
+        co[:nzh, :nzw] = rng.integers(-(1 << 12), 1 << 12, size=(nzh, nzw))
+        e = co.copy()
+        assert orc.orc_itx(trh, trv, lw, lh, e.ctypes.data, nzw, nzh, 15, 10) == 0
+        j = arr[i]
+        j.log2_w, j.log2_h, j.nzw, j.nzh, j.range, j.bd, j.store_coeffs = lw, lh, nzw, nzh, 15, 10, 1
+        j.trh, j.trv = 2 - trh if trh else 1, 0                  # deliberately wrong: the device must ignore these
+        j.mts_flags, j.tu_flags, j.mts_idx, j.lfnst_idx, j.c_idx = abi.ITX_DERIVE_TYPE, flags, mts, lf, c
+        bufs.append(batch.DeviceBuffer.from_host(co)); want.append(e)
+        j.coeffs = bufs[-1].ptr
+    # generic entry for all of them, then the shape-specialised entry per shape
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_itx_batch(None, 10, d_jobs.ptr, n, 10)
+    dev.vvc355_stream_sync(None)
+    for i in range(n):
+        assert np.array_equal(bufs[i].to_host(np.int32, want[i].shape), want[i]), ("generic", i)

@@ -1,0 +1,78 @@
+"""GPU parity of the RECON stage driver (vvc355_recon_frame_pass): in-order walk of every CTU's coding units — intra prediction
+reading neighbours written by earlier blocks of the same and of neighbouring CTUs, then the residual — with CTUs released in
+wavefront order, against the oracle's restatement of ff_vvc_reconstruct that runs the same command lists in decoding order
+(vvc_intra.c:188-274, :480-527, :574-714; vvc_thread.c:156-184)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import bipred_cases as bc
+import recon_cases
+from conftest import P
+from ffvvc_amd import abi, batch
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
+    orc.orc_recon_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.ReconFrame)]
+    orc.orc_recon_frame_pass.restype = None
+    hs, vs = fmt
+    isz = 1 if bd == 8 else 2
+    work = recon_cases.ReconWork(rng, w, h, ctb_log2, hs, vs, **kw)
+    dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
+    planes = [bc.smooth_picture(rng, ph, pw, bd, scale=16) for (pw, ph) in dims]
+    resid = rng.integers(-(1 << (bd - 3)), 1 << (bd - 3), size=max(1, work.resid_len)).astype(np.int32)
+    # oracle on host copies
+    want = [p.copy() for p in planes]
+    hc = work.bind(resid.ctypes.data)
+    hf = work.frame([P(p) for p in want], [d[0] * isz for d in dims], hc.ctypes.data, work.ctus.ctypes.data, work.order.ctypes.data, 0,
+                    work.slice_idx.ctypes.data, work.col_bd.ctypes.data, work.row_bd.ctypes.data, wpp=kw.get("n_slices", 1) > 2, collocated=int(rng.integers(0, 2)))
+    orc.orc_recon_frame_pass(bd, ctypes.byref(hf))
+    # device
+    pitched = [batch.to_pitched(p) for p in planes]
+    d_planes = [batch.DeviceBuffer.from_host(p) for p in pitched]
+    d_res = batch.DeviceBuffer.from_host(resid)
+    dcmd = work.bind(d_res.ptr)
+    d_cmds, d_ctus, d_order = batch.DeviceBuffer.from_host(dcmd.view(np.uint8)), batch.DeviceBuffer.from_host(work.ctus.view(np.uint8)), batch.DeviceBuffer.from_host(work.order if len(work.order) else np.zeros(1, np.int32))
+    d_state = batch.DeviceBuffer(dev.vvc355_recon_state_bytes(work.ncx * work.ncy))
+    d_slice, d_col, d_row = batch.DeviceBuffer.from_host(work.slice_idx), batch.DeviceBuffer.from_host(work.col_bd), batch.DeviceBuffer.from_host(work.row_bd)
+    df = work.frame([b.ptr for b in d_planes], [p.shape[1] * isz for p in pitched], d_cmds.ptr, d_ctus.ptr, d_order.ptr, d_state.ptr,
+                    d_slice.ptr, d_col.ptr, d_row.ptr, wpp=hf.wpp, collocated=hf.collocated)
+    d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
+    for rep in range(2):           # twice: the second pass must find its scheduling state reset (and reproduce the result from the same start)
+        for b, p in zip(d_planes, pitched):
+            dev.vvc355_upload(b.ptr, p.ctypes.data, p.nbytes)
+        dev.vvc355_recon_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df))
+        dev.vvc355_stream_sync(None)
+        for c in range(3):
+            got = d_planes[c].to_host(pitched[c].dtype, pitched[c].shape)[:, :dims[c][0]]
+            bad = np.argwhere(got != want[c])
+            assert len(bad) == 0, (f"pass {rep} bd={bd} {w}x{h} ctb={1 << ctb_log2} fmt={fmt} component {c}: {len(bad)} samples differ, first at (y, x) = {bad[0].tolist()}; "
+                                   f"{len(work.cmds)} commands in {len(work.order)} CTUs")
+    changed = sum(int((want[c] != planes[c]).sum()) for c in range(3))
+    return work, changed
+
+
+@pytest.mark.parametrize("bd,fmt,ctb_log2", [(10, (1, 1), 7), (8, (1, 1), 6), (12, (0, 0), 5), (10, (1, 0), 6), (8, (1, 1), 7)])
+def test_recon_all_intra_wavefront(dev, orc, bd, fmt, ctb_log2):
+    """Every coding unit intra: each block's prediction depends on blocks reconstructed just before it, inside the CTU and across
+    CTU borders (left, upper-left, upper, upper-right) — any ordering or visibility error shows up as a mismatch."""
+    rng = np.random.default_rng(0x5EED0E00 + bd + 16 * ctb_log2 + fmt[0] + 2 * fmt[1])
+    work, changed = run_case(dev, orc, rng, bd, 456, 264, ctb_log2, fmt, intra_frac=1.0, n_slices=3 if ctb_log2 < 7 else 1, tiles=ctb_log2 == 6)
+    kinds = work.cmds["kind"]
+    assert (kinds == abi.RECON_PRED).sum() > 50 and (kinds == abi.RECON_CCLM).sum() > 3 and (kinds == abi.RECON_RESID).sum() > 50
+    assert work.cmds["is_mip"].sum() > 0 and work.cmds["isp_split"].sum() > 0 and (work.cmds["joint"] != 0).sum() > 0
+    assert changed > 456 * 264 // 2
+
+
+@pytest.mark.parametrize("bd", [10])
+def test_recon_mixed_picture(dev, orc, bd):
+    """Inter and intra coding units mixed, whole CTUs without intra work among them (those are skipped by the scheduler)."""
+    rng = np.random.default_rng(0x5EED0E77)
+    intra_ctu = rng.random(12 * 7) < 0.4
+    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_frac=0.5, intra_ctu=None)
+    assert 0 < len(work.order) <= 12 * 7
+    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_ctu=intra_ctu)
+    assert 0 < len(work.order) < 12 * 7
