@@ -283,7 +283,7 @@ def build_chain(lib, torch, fr):
     # the residual adds through the in-order wavefront pass further down
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import recon_cases
-    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.8, 0.25))
+    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape

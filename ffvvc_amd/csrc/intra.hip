@@ -7,6 +7,7 @@
 //
 // One workgroup per block: reference samples live in LDS as uint16 with the reference's origin offset (MAX_TB_SIZE + 3),
 // lanes sweep the block row-major so that every row store is contiguous.
+#include <type_traits>
 #include "common.hpp"
 #include "runtime.hpp"
 #include "../../include/vvc_mi355.h"
@@ -72,6 +73,22 @@ struct LRef {
     __device__ __forceinline__ int operator()(int i) const { return p[i]; }
 };
 
+// sample-plane accessors, offsets in PIXELS from the accessor's origin: a component plane in HBM, or the RECON stage driver's CTU
+// tile in LDS (uint16 samples); at(off) moves the origin
+template <int BD> struct GPix {
+    uint8_t *p;
+    __device__ __forceinline__ int ld(ptrdiff_t off) const { return ld_px<BD>(p, off); }
+    __device__ __forceinline__ void st(ptrdiff_t off, int v) const { st_px<BD>(p, off, v); }
+    __device__ __forceinline__ GPix at(ptrdiff_t off) const { return GPix{ p + off * (ptrdiff_t)sizeof(typename Px<BD>::type) }; }
+};
+struct LPix {
+    uint16_t *p;
+    int base;
+    __device__ __forceinline__ int ld(int off) const { return p[base + off]; }
+    __device__ __forceinline__ void st(int off, int v) const { p[base + off] = (uint16_t)v; }
+    __device__ __forceinline__ LPix at(int off) const { return LPix{ p, base + off }; }
+};
+
 // ------------------------------------------------------------------------------------------------ leaf predictors
 // Executed by a group of NT lanes (a wave or the whole workgroup); `tid` is the lane's index in its group.
 
@@ -81,20 +98,20 @@ template <int NT> __device__ __forceinline__ void group_sync()
     else __syncthreads();
 }
 
-template <int BD, int NT, typename R>
-__device__ void pred_planar(int tid, uint8_t *src, int stride, R top, R left, int w, int h)
+template <int BD, int NT, typename R, typename PX>
+__device__ void pred_planar(int tid, PX src, int stride, R top, R left, int w, int h)
 {
     const int lw = ilog2i(w), lh = ilog2i(h);
     for (int i = tid; i < w * h; i += NT) {
         const int y = i >> lw, x = i & (w - 1);           // block sides are powers of two
         const int pv = ((h - 1 - y) * top(x) + (y + 1) * left(h)) << lw;
         const int ph = ((w - 1 - x) * left(y) + (x + 1) * top(w)) << lh;
-        st_px<BD>(src, x + __mul24(stride, y), (pv + ph + w * h) >> (lw + lh + 1));
+        src.st(x + __mul24(stride, y), (pv + ph + w * h) >> (lw + lh + 1));
     }
 }
 
-template <int BD, int NT, typename R>
-__device__ void pred_dc(int tid, uint8_t *src, int stride, R top, R left, int w, int h, int *scratch)
+template <int BD, int NT, typename R, typename PX>
+__device__ void pred_dc(int tid, PX src, int stride, R top, R left, int w, int h, int *scratch)
 {
     if (tid == 0) {
         const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
@@ -108,18 +125,18 @@ __device__ void pred_dc(int tid, uint8_t *src, int stride, R top, R left, int w,
     const int lw4 = ilog2i(w4);
     for (int i = tid; i < w4 * h; i += NT) {
         const int y = i >> lw4, x = i & (w4 - 1);
-        st_px<BD>(src, x + __mul24(stride, y), dc);
+        src.st(x + __mul24(stride, y), dc);
     }
 }
 
-template <int BD, int NT, typename R>
-__device__ void pred_vh(int tid, uint8_t *src, int stride, R ref, int w, int h, bool vertical)
+template <int BD, int NT, typename R, typename PX>
+__device__ void pred_vh(int tid, PX src, int stride, R ref, int w, int h, bool vertical)
 {
     const int ww = vertical ? w : (w + 3) & ~3;           // pred_h stores whole groups of 4 (:885)
     const int lww = ilog2i(ww);
     for (int i = tid; i < ww * h; i += NT) {
         const int y = i >> lww, x = i & (ww - 1);
-        st_px<BD>(src, x + __mul24(stride, y), vertical ? ref(x) : ref(y));
+        src.st(x + __mul24(stride, y), vertical ? ref(x) : ref(y));
     }
 }
 
@@ -135,8 +152,8 @@ __device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx,
     return ((32 - fact) * ref(i + 1) + fact * ref(i + 2) + 16) >> 5;
 }
 
-template <int BD, int NT, typename R>
-__device__ void pred_angular(int tid, uint8_t *src, int stride, R top, R left, int w, int h, bool vertical,
+template <int BD, int NT, typename R, typename PX>
+__device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, int h, bool vertical,
                              int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
 {
     const int angle = intra_pred_angle(mode);
@@ -164,13 +181,13 @@ __device__ void pred_angular(int tid, uint8_t *src, int stride, R top, R left, i
                 pred = clip_px<BD>(pred + (((t - pred) * (32 >> min(31, (y * 2) >> nscale)) + 32) >> 6));
             }
         }
-        st_px<BD>(src, x + __mul24(stride, y), pred);
+        src.st(x + __mul24(stride, y), pred);
     }
 }
 
 // MIP (:708-824).  `red` = 16 ints of LDS scratch.
-template <int BD, int NT, typename R>
-__device__ void pred_mip(int tid, uint8_t *src, int stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
+template <int BD, int NT, typename R, typename PX>
+__device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
 {
     const int size_id = (w == 4 && h == 4) ? 0 : ((w == 4 || h == 4) || (w == 8 && h == 8)) ? 1 : 2;
     const int bsize = size_id == 0 ? 2 : 4, psize = size_id == 2 ? 8 : 4;
@@ -208,16 +225,16 @@ __device__ void pred_mip(int tid, uint8_t *src, int stride, R top, R left, int w
             p += red[i] * matrix[(y * psize + x) * in_size + i];
         p = clip3(((p + red[14]) >> 6) + red[15], 0, (1 << BD) - 1);
         const int cx = transposed ? y : x, cy = transposed ? x : y;
-        st_px<BD>(src, (up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
+        src.st((up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
     }
     group_sync<NT>();
     for (int t = tid; up_h > 1 && t < psize; t += NT) {            // one lane per row that holds reduced samples
         const int row = up_v - 1 + t * up_v;
         int before = left(row);
         for (int j = 0; j < psize; j++) {
-            const int after = ld_px<BD>(src, (j + 1) * up_h - 1 + stride * row);
+            const int after = src.ld((j + 1) * up_h - 1 + stride * row);
             for (int k = 1; k < up_h; k++)
-                st_px<BD>(src, j * up_h + k - 1 + stride * row, ((up_h - k) * before + k * after + up_h / 2) / up_h);
+                src.st(j * up_h + k - 1 + stride * row, ((up_h - k) * before + k * after + up_h / 2) / up_h);
             before = after;
         }
     }
@@ -225,9 +242,9 @@ __device__ void pred_mip(int tid, uint8_t *src, int stride, R top, R left, int w
     for (int x = tid; up_v > 1 && x < w; x += NT) {                // one lane per column
         int before = top(x);
         for (int j = 0; j < psize; j++) {
-            const int after = ld_px<BD>(src, x + stride * ((j + 1) * up_v - 1));
+            const int after = src.ld(x + stride * ((j + 1) * up_v - 1));
             for (int k = 1; k < up_v; k++)
-                st_px<BD>(src, x + stride * (j * up_v + k - 1), ((up_v - k) * before + k * after + up_v / 2) / up_v);
+                src.st(x + stride * (j * up_v + k - 1), ((up_v - k) * before + k * after + up_v / 2) / up_v);
             before = after;
         }
     }
@@ -246,14 +263,15 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
 {
     __shared__ int scratch[16];
     GRef<BD> top{ a.top }, left{ a.left };
+    const GPix<BD> dst{ a.src };
     switch (a.kind) {
-    case 0: pred_planar<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h); break;
-    case 1: pred_dc<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, scratch); break;
-    case 2: pred_vh<BD, 256>(threadIdx.x, a.src, a.stride, top, a.w, a.h, true); break;
-    case 3: pred_vh<BD, 256>(threadIdx.x, a.src, a.stride, left, a.w, a.h, false); break;
-    case 4: pred_angular<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, true, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
-    case 5: pred_angular<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, false, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
-    default: pred_mip<BD, 256>(threadIdx.x, a.src, a.stride, top, left, a.w, a.h, a.mip_mode, a.mip_transposed, scratch); break;
+    case 0: pred_planar<BD, 256>(threadIdx.x, dst, a.stride, top, left, a.w, a.h); break;
+    case 1: pred_dc<BD, 256>(threadIdx.x, dst, a.stride, top, left, a.w, a.h, scratch); break;
+    case 2: pred_vh<BD, 256>(threadIdx.x, dst, a.stride, top, a.w, a.h, true); break;
+    case 3: pred_vh<BD, 256>(threadIdx.x, dst, a.stride, left, a.w, a.h, false); break;
+    case 4: pred_angular<BD, 256>(threadIdx.x, dst, a.stride, top, left, a.w, a.h, true, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    case 5: pred_angular<BD, 256>(threadIdx.x, dst, a.stride, top, left, a.w, a.h, false, a.c_idx, a.mode, a.ref_idx, a.filter_flag, a.need_pdpc); break;
+    default: pred_mip<BD, 256>(threadIdx.x, dst, a.stride, top, left, a.w, a.h, a.mip_mode, a.mip_transposed, scratch); break;
     }
 }
 
@@ -263,13 +281,14 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
 // NT = 32: half a wave per block (w*h <= 64), eight blocks per workgroup; NT = 64: one wave per block (w*h <= 256), four per
 // workgroup; both with wave-level synchronisation only.  NT = 256: one workgroup per block.
 // the whole slot for one block, executed by a group of NT lanes (tid = lane's index in the group); arr = four edge arrays in LDS
-template <int BD, int NT>
-__device__ void intra_pred_body(const vvc355_intra_job &j, uint16_t (*arr)[kEdgeLen], int *scratch, int tid)
+// plane = accessor of the component plane's sample (0, 0); stride in pixels
+template <int BD, int NT, typename PX>
+__device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_px, uint16_t (*arr)[kEdgeLen], int *scratch, int tid)
 {
-    const int stride = j.stride / (int)sizeof(typename Px<BD>::type);      // pixels; int keeps the row offsets full-rate 24-bit multiplies
+    const int stride = stride_px;
     const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
-    uint8_t *src = (uint8_t *)j.plane + (ptrdiff_t)(__mul24(j.y, stride) + j.x) * (ptrdiff_t)sizeof(typename Px<BD>::type);
+    const PX src = plane.at(__mul24(j.y, stride) + j.x);
     const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
     uint16_t *left = arr[0] + kEdgeOrg, *top = arr[1] + kEdgeOrg, *fleft = arr[2] + kEdgeOrg, *ftop = arr[3] + kEdgeOrg;
 
@@ -288,7 +307,7 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, uint16_t (*arr)[kEdge
         utop = top_size = refw; uleft = left_size = refh;
     }
     const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
-#define GETP(x, y) ld_px<BD>(src, (x) + __mul24(stride, (y)))
+#define GETP(x, y) src.ld((x) + __mul24(stride, (y)))
     for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
     for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)GETP(i, ref_line);
     // the corner samples -1 .. ref_line (at most four) go out with the edge loads, on the last lanes of the group
@@ -375,7 +394,7 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, uint16_t (*arr)[kEdge
                 wl = mode == 50 ? 32 >> min((x << 1) >> scale, 31) : 0;
                 wt = mode == 18 ? 32 >> min((y << 1) >> scale, 31) : 0;
             }
-            st_px<BD>(src, x + __mul24(stride, y), clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
+            src.st(x + __mul24(stride, y), clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
         }
     }
 #undef GETP
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
         return;
     // a wave (or the workgroup) per job: the descriptor comes through the scalar cache; two jobs per wave: per-lane loads
     const vvc355_intra_job j = NT >= 64 ? load_uniform(jobs + __builtin_amdgcn_readfirstlane(ji)) : jobs[ji];
-    intra_pred_body<BD, NT>(j, arr_all[sub], scratch_all[sub], threadIdx.x % NT);
+    intra_pred_body<BD, NT>(j, GPix<BD>{ (uint8_t *)j.plane }, j.stride / (int)sizeof(typename Px<BD>::type), arr_all[sub], scratch_all[sub], threadIdx.x % NT);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -545,14 +564,12 @@ void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
 
 namespace vvc355 {
 
-template <int BD>
-__device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, int cx, int cy)
+template <int BD, typename PX>
+__device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, PX luma, int s, int cx, int cy)
 {
-    const uint8_t *luma = (const uint8_t *)j.luma;
-    const ptrdiff_t s = j.luma_stride / (ptrdiff_t)sizeof(typename Px<BD>::type);
     const int hs = j.hs, vs = j.vs;
-    const ptrdiff_t o = (ptrdiff_t)(j.y0 + (cy << vs)) * s + j.x0 + (cx << hs);
-#define L(dx, dy) ld_px<BD>(luma, o + (dx) + (dy) * s)
+    const int o = (j.y0 + (cy << vs)) * s + j.x0 + (cx << hs);
+#define L(dx, dy) luma.ld(o + (dx) + (dy) * s)
     if (!hs && !vs)
         return L(0, 0);
     const int lx = (cx || j.avail_l) ? -1 : 0;
@@ -567,26 +584,24 @@ __device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, int cx, in
 }
 
 // the whole slot for one block, executed by the workgroup; prm = six ints in LDS (a[2], b[2], k[2])
-template <int BD>
-__device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
+// luma / cb / cr = accessors of the planes' sample (0, 0), strides in pixels (the job's addresses and strides are not used)
+template <int BD, int NT, typename PX>
+__device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX cr, int cs0, int cs1, int *prm, int tid)
 {
-    using px_t = typename Px<BD>::type;
     const int hs = j.hs, vs = j.vs;
     const int x = j.x0 >> hs, y = j.y0 >> vs, w = j.width >> hs, h = j.height >> vs;
     const int avail_t = j.avail_t, avail_l = j.avail_l;
-    uint8_t *cpl[2] = { (uint8_t *)j.cb, (uint8_t *)j.cr };
-    const ptrdiff_t cs[2] = { j.cb_stride / (ptrdiff_t)sizeof(px_t), j.cr_stride / (ptrdiff_t)sizeof(px_t) };
+    const PX cpl[2] = { cb, cr };
+    const int cs[2] = { cs0, cs1 };
 
     if (!avail_t && !avail_l) {
-        for (int i = threadIdx.x; i < 2 * w * h; i += blockDim.x) {
+        for (int i = tid; i < 2 * w * h; i += NT) {
             const int c = i / (w * h), r = i - c * w * h, yy = r / w, xx = r - yy * w;
-            st_px<BD>(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, 1 << (BD - 1));
+            cpl[c].st((y + yy) * cs[c] + x + xx, 1 << (BD - 1));
         }
         return;
     }
-    if (threadIdx.x == 0) {
-        const uint8_t *luma = (const uint8_t *)j.luma;
-        const ptrdiff_t ls = j.luma_stride / (ptrdiff_t)sizeof(px_t);
+    if (tid == 0) {
         int a[2] = { 0, 0 }, b[2] = { 1 << (BD - 1), 1 << (BD - 1) }, k[2] = { 0, 0 };
         int cnt[2] = { 0, 0 }, pos[2][4], have = 0;
         const int lt = j.mode == 81;
@@ -609,14 +624,14 @@ __device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
         if (have) {
             int sel[3][8];
             for (int c = 0; c < 3; c++) for (int i = 0; i < 8; i++) sel[c][i] = 0;
-            const ptrdiff_t lo = (ptrdiff_t)j.y0 * ls + j.x0;
-#define LP(off) ld_px<BD>(luma, (off))
+            const int lo = j.y0 * ls + j.x0;
+#define LP(off) luma.ld((int)(off))
             for (int i = 0; i < cnt[0]; i++) {
                 if (!hs && !vs) { sel[0][i] = LP(lo - avail_t * ls + pos[0][i]); continue; }
                 const int xx = pos[0][i] << hs;
                 const int has_left = xx || avail_l;
                 if (vs && !j.ctu_boundary) {
-                    const ptrdiff_t o = lo - 2 * ls + xx;
+                    const int o = lo - 2 * ls + xx;
                     const int l = has_left ? LP(o - 1) : LP(o);
                     if (j.collocated)
                         sel[0][i] = (LP(o - ls) + l + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
@@ -625,15 +640,15 @@ __device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
                         sel[0][i] = (l + l1 + 2 * (LP(o) + LP(o + ls)) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
                     }
                 } else {
-                    const ptrdiff_t o = lo - ls + xx;
+                    const int o = lo - ls + xx;
                     const int l = has_left ? LP(o - 1) : LP(o);
                     sel[0][i] = (l + 2 * LP(o) + LP(o + 1) + 2) >> 2;
                 }
             }
             for (int i = 0; i < cnt[1]; i++) {
-                if (!hs && !vs) { sel[0][cnt[0] + i] = LP(lo - avail_l + (ptrdiff_t)pos[1][i] * ls); continue; }
+                if (!hs && !vs) { sel[0][cnt[0] + i] = LP(lo - avail_l + pos[1][i] * ls); continue; }
                 const int yy = pos[1][i] << vs;
-                const ptrdiff_t o = lo - (1 + hs) * avail_l + (ptrdiff_t)yy * ls, l = o - avail_l;
+                const int o = lo - (1 + hs) * avail_l + yy * ls, l = o - avail_l;
                 int p;
                 if (!vs)
                     p = (LP(l) + 2 * LP(o) + LP(o + 1) + 2) >> 2;
@@ -647,9 +662,9 @@ __device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
 #undef LP
             for (int c = 0; c < 2; c++) {
                 for (int i = 0; i < cnt[0]; i++)
-                    sel[c + 1][i] = ld_px<BD>(cpl[c], (ptrdiff_t)(y - 1) * cs[c] + x + pos[0][i]);
+                    sel[c + 1][i] = cpl[c].ld((y - 1) * cs[c] + x + pos[0][i]);
                 for (int i = 0; i < cnt[1]; i++)
-                    sel[c + 1][cnt[0] + i] = ld_px<BD>(cpl[c], (ptrdiff_t)(y + pos[1][i]) * cs[c] + x - 1);
+                    sel[c + 1][cnt[0] + i] = cpl[c].ld((y + pos[1][i]) * cs[c] + x - 1);
             }
             if (cnt[0] + cnt[1] == 2)
                 for (int c = 0; c < 3; c++) {
@@ -686,13 +701,13 @@ __device__ void cclm_body(const vvc355_cclm_job &j, int *prm)
         }
         prm[0] = a[0]; prm[1] = a[1]; prm[2] = b[0]; prm[3] = b[1]; prm[4] = k[0]; prm[5] = k[1];
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    group_sync<NT>();
+    for (int i = tid; i < w * h; i += NT) {
         const int yy = i / w, xx = i - yy * w;
-        const int dsy = cclm_ds_luma<BD>(j, xx, yy);
+        const int dsy = cclm_ds_luma<BD>(j, luma, ls, xx, yy);
 #pragma unroll
         for (int c = 0; c < 2; c++)
-            st_px<BD>(cpl[c], (ptrdiff_t)(y + yy) * cs[c] + x + xx, clip_px<BD>(((dsy * prm[c]) >> prm[4 + c]) + prm[2 + c]));
+            cpl[c].st((y + yy) * cs[c] + x + xx, clip_px<BD>(((dsy * prm[c]) >> prm[4 + c]) + prm[2 + c]));
     }
 }
 
@@ -701,7 +716,9 @@ __global__ __launch_bounds__(256) void cclm_kernel(const vvc355_cclm_job *__rest
 {
     __shared__ int prm[6];
     const vvc355_cclm_job j = load_uniform(jobs + (blockIdx.x));
-    cclm_body<BD>(j, prm);
+    constexpr int PXS = (int)sizeof(typename Px<BD>::type);
+    cclm_body<BD, 256>(j, GPix<BD>{ (uint8_t *)j.luma }, j.luma_stride / PXS, GPix<BD>{ (uint8_t *)j.cb }, GPix<BD>{ (uint8_t *)j.cr },
+                       j.cb_stride / PXS, j.cr_stride / PXS, prm, threadIdx.x);
 }
 
 template <int BD>
@@ -813,7 +830,7 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 // order (intra prediction reading what earlier blocks wrote, then the transform unit's residual), CTUs are released in wavefront
 // order.  See include/vvc_mi355.h (vvc355_recon_frame) for the command set and for what stays in the batched transform stage.
 //
-// Scheduling: workgroups take tickets (one atomic per workgroup) and process the CTUs that have commands in raster order of their
+// Scheduling: workgroups (one wave each) take tickets (one atomic per workgroup) and process the CTUs that have commands in raster order of their
 // tickets, so every CTU a workgroup waits for belongs to a workgroup that is already running or done: no deadlock whatever the
 // dispatch order.  A CTU waits for its left, upper-left, upper and upper-right neighbours (those with commands; the others carry
 // only inter prediction + residuals finished by earlier launches).  Hand-off between workgroups: all stores of the CTU, every
@@ -825,30 +842,40 @@ namespace vvc355 {
 
 struct ReconArea { int16_t x, y, w, h; };
 struct ReconLds {
-    uint16_t arr[4][kEdgeLen];
-    int scratch[16];
-    int prm[8];
+    uint16_t arr[2][4][kEdgeLen];     // edge arrays, scratch and CCLM parameters per role (luma wave, chroma wave)
+    int scratch[2][16];
+    int prm[2][8];
     ReconArea ras[2][1024];           // MAX_PARTS_IN_CTU (vvc_ctu.h:38) reconstructed areas per channel type, in decoding order
-    int num_ras[2];
+    volatile int luma_done;           // commands the luma wave has passed (the chroma wave waits on it before CCLM)
     int bc[8];
 };
 struct ReconCtx { int ctb_up, ctb_left, ctb_up_left, end_of_tiles_x; };
 
-// get_reconstructed_area (vvc_intra.c:574-589), one lane
-__device__ int recon_find_area(const ReconLds &L, int ch, int x, int y)
+// get_reconstructed_area (vvc_intra.c:574-589) by one wave, every lane with the same (x, y): the list is scanned from its end, 64
+// areas per step; the first event in list order decides — a hit returns that area, an area wholly up-left of the point ends the
+// search ("it's too far away, no need check it") — exactly the serial walk's result
+__device__ int recon_find_area(const ReconLds &L, int ch, int n, int x, int y, int lane)
 {
-    for (int i = L.num_ras[ch] - 1; i >= 0; i--) {
-        const ReconArea a = L.ras[ch][i];
-        const int r = a.x + a.w, b = a.y + a.h;
-        if (a.x <= x && x < r && a.y <= y && y < b)
-            return i;
-        if (x >= r && y >= b)             // "it's too far away, no need check it"
-            break;
+    for (int base = n - 1; base >= 0; base -= 64) {
+        const int i = base - lane;
+        bool hit = false, stop = false;
+        if (i >= 0) {
+            const ReconArea a = L.ras[ch][i];
+            const int r = a.x + a.w, b = a.y + a.h;
+            hit = a.x <= x && x < r && a.y <= y && y < b;
+            stop = x >= r && y >= b;
+        }
+        const unsigned long long hm = __ballot(hit), sm = __ballot(stop);
+        const int fh = hm ? __builtin_ctzll(hm) : 64, fs = sm ? __builtin_ctzll(sm) : 64;
+        if (fh < fs)
+            return base - fh;
+        if (fs < 64)
+            return -1;
     }
     return -1;
 }
-// ff_vvc_get_top_available (vvc_intra.c:591-620), one lane
-__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_x0, int x, int y, int target, int c_idx)
+// ff_vvc_get_top_available (vvc_intra.c:591-620), one wave (uniform arguments, uniform result)
+__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int n_ras, int cu_x0, int x, int y, int target, int c_idx, int lane)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int end_of_ctb_x = ((cu_x0 >> f.ctb_log2) + 1) << f.ctb_log2;
@@ -864,15 +891,15 @@ __device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &
     }
     target = max(0, min(target, max_x - x));
     int px = x, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, px, y - 1)) >= 0) {
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, px, y - 1, lane)) >= 0) {
         const int sz = min(target, L.ras[c_idx > 0][i].x + L.ras[c_idx > 0][i].w - px);
         px += sz;
         target -= sz;
     }
     return px - x;
 }
-// ff_vvc_get_left_available (vvc_intra.c:622-648), one lane
-__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_y0, int x, int y, int target, int c_idx)
+// ff_vvc_get_left_available (vvc_intra.c:622-648), one wave
+__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int n_ras, int cu_y0, int x, int y, int target, int c_idx, int lane)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int x0b = x & ((1 << (f.ctb_log2 - hs)) - 1);
@@ -884,7 +911,7 @@ __device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx 
     if (!x0b)
         return target;
     int py = y, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, x - 1, py)) >= 0) {
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, x - 1, py, lane)) >= 0) {
         const int sz = min(target, L.ras[c_idx > 0][i].y + L.ras[c_idx > 0][i].h - py);
         py += sz;
         target -= sz;
@@ -906,29 +933,99 @@ __host__ __device__ inline int wide_angle_mode(int isp_split, int c_idx, int tb_
 
 static constexpr int kReconFlags = 16;        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done
 
+// one wave per CTU and channel type: a CTU's blocks are a dependent chain (each reads what the previous ones wrote), so more lanes
+// per block would only add workgroup barriers to every link.  TILE (4:2:0, CTUs up to 128x128): the CTU's three component blocks live in LDS for the whole
+// walk, together with the four rows above (reaching one CTU to the right: above-right references) and the four columns to the
+// left that reference-line selection can address — loaded once after the neighbours' flags, written back once before this CTU's
+// flag.  Every link of the chain then costs LDS latency instead of an HBM / L2 round trip.  Other chroma formats walk on the
+// planes in HBM (the wave's own stores are made visible to its later loads by s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void recon_sync_mem()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+static constexpr int kApr = 4;                                    // apron rows above / columns to the left (ref_idx 3 reads line -4)
+static constexpr int kTileLumaP = kApr + 2 * 128 + 4, kTileLumaH = kApr + 128;          // 264 x 132
+static constexpr int kTileChromaP = kApr + 2 * 64 + 4, kTileChromaH = kApr + 64;        // 136 x 68
+static constexpr int kTileSamples = kTileLumaP * kTileLumaH + 2 * kTileChromaP * kTileChromaH;
+
+// rows -kApr .. ch - 1 of one component around the CTU at (ox, oy): above the CTU 2 * ctb + kApr columns, inside it ctb + kApr;
+// coordinates clamped to the picture (samples outside it are never referenced: the availability process stops there)
 template <int BD>
-__global__ __launch_bounds__(256) void recon_wavefront_kernel(const vvc355_recon_frame *__restrict__ fp)
+__device__ void recon_tile_load(uint16_t *tile, int pitch, const uint8_t *plane, int stride, int ox, int oy, int ch, int ctb, int pic_w, int pic_h, int lane)
+{
+    using px_t = typename Px<BD>::type;
+    const int nk_top = (kApr + 2 * ctb) / 4, nk_in = (kApr + ctb) / 4;
+    const int total = kApr * nk_top + ch * nk_in;
+    for (int i = lane; i < total; i += 64) {
+        int r, k;
+        if (i < kApr * nk_top) { r = i / nk_top; k = i - r * nk_top; r -= kApr; }
+        else { const int q = i - kApr * nk_top; r = q / nk_in; k = q - r * nk_in; }
+        const int y = clip3(oy + r, 0, pic_h - 1), x0 = ox - kApr + 4 * k;
+        uint16_t *d = tile + (r + kApr) * pitch + 4 * k;
+        if (x0 >= 0 && x0 + 3 < pic_w) {
+            const uint8_t *p = plane + row_off(y, stride) + x0 * (int)sizeof(px_t);
+            if (BD > 8) {
+                *(uint2 *)d = gld<uint2>(p);
+            } else {
+                const uint32_t q = gld<uint32_t>(p);
+                *(uint2 *)d = make_uint2(__builtin_amdgcn_perm(0, q, 0x0c010c00u), __builtin_amdgcn_perm(0, q, 0x0c030c02u));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                d[e] = (uint16_t)ld_px<BD>(plane + row_off(y, stride), clip3(x0 + e, 0, pic_w - 1));
+        }
+    }
+}
+// the CTU's own cw x ch samples back to the plane
+template <int BD>
+__device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane, int stride, int ox, int oy, int cw, int ch, int lane)
+{
+    using px_t = typename Px<BD>::type;
+    const int nk = cw / 4, total = ch * nk;
+    for (int i = lane; i < total; i += 64) {
+        const int r = i / nk, k = i - r * nk;
+        const uint2 v = *(const uint2 *)(tile + (r + kApr) * pitch + kApr + 4 * k);
+        uint8_t *p = plane + row_off(oy + r, stride) + (ox + 4 * k) * (int)sizeof(px_t);
+        if (BD > 8)
+            gst<uint2>(p, v);
+        else
+            gst<uint32_t>(p, __builtin_amdgcn_perm(v.y, v.x, 0x06040200u));
+    }
+}
+
+template <int BD, bool TILE>
+__global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon_frame *__restrict__ fp)
 {
     __shared__ ReconLds L;
+    __shared__ __attribute__((aligned(16))) uint16_t tiles[TILE ? kTileSamples : 8];
     using px_t = typename Px<BD>::type;
+    using PX = typename std::conditional<TILE, LPix, GPix<BD>>::type;
     const vvc355_recon_frame f = load_uniform(fp);
     int *state = (int *)f.state;
-    const int tid = threadIdx.x;
-    if (tid == 0)
+    // two waves per CTU: wave 0 walks the luma commands, wave 1 the chroma commands.  The two chains only meet at CCLM (chroma
+    // predicted from the coding unit's reconstructed luma): the chroma wave waits there until the luma wave has passed that command.
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
         L.bc[0] = atomicAdd(&state[0], 1);
+        L.luma_done = 0;
+    }
     __syncthreads();
-    const int ticket = L.bc[0];
+    const int ticket = __builtin_amdgcn_readfirstlane(L.bc[0]);
     if (ticket >= f.n_work)
         return;
     const int rs = __builtin_amdgcn_readfirstlane(gld<int>((const int *)f.order + ticket));
     const vvc355_recon_ctu *ctus = (const vvc355_recon_ctu *)f.ctus;
     const vvc355_recon_ctu ctu = load_uniform(ctus + rs);
     const int ncx = f.ctb_width, ry = rs / ncx, rx = rs - ry * ncx;
+    const int ctb = 1 << f.ctb_log2;
     ReconCtx cx;
     {
         // ff_vvc_decode_neighbour (vvc_ctu.c:2468-2495)
         const int16_t *slice_idx = (const int16_t *)f.slice_idx, *col_bd = (const int16_t *)f.ctb_to_col_bd, *row_bd = (const int16_t *)f.ctb_to_row_bd;
-        const int ctb = 1 << f.ctb_log2;
         const bool left_tile = rx > 0 && gld<int16_t>(col_bd + rx) != gld<int16_t>(col_bd + rx - 1);
         const bool upper_tile = ry > 0 && gld<int16_t>(row_bd + ry) != gld<int16_t>(row_bd + ry - 1);
         const bool upper_slice = ry > 0 && gld<int16_t>(slice_idx + rs) != gld<int16_t>(slice_idx + rs - ncx);
@@ -940,7 +1037,7 @@ __global__ __launch_bounds__(256) void recon_wavefront_kernel(const vvc355_recon
         cx.ctb_up_left = cx.ctb_left && cx.ctb_up;
     }
     // wait for the neighbours this CTU reads: left, upper-left, upper, upper-right (those that have commands)
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const int dep[4] = { rx > 0 ? rs - 1 : -1, (rx > 0 && ry > 0) ? rs - ncx - 1 : -1, ry > 0 ? rs - ncx : -1, (ry > 0 && rx + 1 < ncx) ? rs - ncx + 1 : -1 };
         for (int d = 0; d < 4; d++) {
             if (dep[d] < 0 || gld<uint32_t>(&ctus[dep[d]].n_cmd) == 0)
@@ -950,39 +1047,78 @@ __global__ __launch_bounds__(256) void recon_wavefront_kernel(const vvc355_recon
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        L.num_ras[0] = L.num_ras[1] = 0;
     }
     __syncthreads();
 
+    // the three planes as the walk sees them: accessor of sample (0, 0) + stride in pixels
+    PX pl[3];
+    int ps[3];
+    uint16_t *tile_c[3] = { tiles, tiles + kTileLumaP * kTileLumaH, tiles + kTileLumaP * kTileLumaH + kTileChromaP * kTileChromaH };
+    const int cw0 = min(ctb, f.width - rx * ctb), ch0 = min(ctb, f.height - ry * ctb);
+    if constexpr (TILE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sh = c ? 1 : 0, pitch = c ? kTileChromaP : kTileLumaP;
+            const int ox = (rx * ctb) >> sh, oy = (ry * ctb) >> sh;
+            if ((c == 0) == (role == 0))       // the luma wave brings in the luma tile, the chroma wave both chroma tiles
+                recon_tile_load<BD>(tile_c[c], pitch, (const uint8_t *)f.plane[c], f.stride[c], ox, oy, ch0 >> sh, ctb >> sh, f.width >> sh, f.height >> sh, tid);
+            pl[c] = LPix{ tile_c[c], (kApr - oy) * pitch + (kApr - ox) };
+            ps[c] = pitch;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            pl[c] = GPix<BD>{ (uint8_t *)f.plane[c] };
+            ps[c] = f.stride[c] / (int)sizeof(px_t);
+        }
+    }
+
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
-    const int ctb_mask = (1 << f.ctb_log2) - 1;
+    const int ctb_mask = ctb - 1;
+    constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
+    // commands are fetched one ahead through the vector-memory path (its counter is not shared with LDS traffic, so the fetch
+    // really overlaps the previous block): lane i holds dword i of the command
+    uint32_t cmd_dw = gld<uint32_t>((const uint32_t *)cmds + min(tid, CMD_DW - 1));
+    int n_own = 0, n_luma_seen = 0;      // areas this wave has recorded in its channel type's list; luma areas recorded before the current command
+    uint16_t (*arr)[kEdgeLen] = L.arr[role];
     for (uint32_t k = 0; k < ctu.n_cmd; k++) {
-        const vvc355_recon_cmd c = load_uniform(cmds + k);
+        vvc355_recon_cmd c;
+        {
+            uint32_t w[CMD_DW];
+#pragma unroll
+            for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)cmd_dw, i);
+            __builtin_memcpy(&c, w, sizeof(c));
+            cmd_dw = gld<uint32_t>((const uint32_t *)(cmds + min(k + 1, ctu.n_cmd - 1)) + min(tid, CMD_DW - 1));
+        }
+        const bool mine = (c.c_idx > 0) == (role == 1);
+        if (!mine) {
+            // the other wave's command; the chroma wave keeps count of the luma areas recorded so far (CCLM's availability reads that list)
+            if (c.kind == VVC355_RECON_MARK)
+                n_luma_seen++;
+            if (role == 0 && tid == 0)
+                L.luma_done = (int)k + 1;
+            continue;
+        }
         if (c.kind == VVC355_RECON_MARK) {
             // add_reconstructed_area (vvc_intra.c:188-206)
-            if (tid == 0) {
-                const int ch = c.c_idx > 0, hs = ch ? f.hs : 0, vs = ch ? f.vs : 0, n = L.num_ras[ch];
-                if (n < 1024) {
-                    L.ras[ch][n] = ReconArea{ (int16_t)(c.x0 >> hs), (int16_t)(c.y0 >> vs), (int16_t)(c.w >> hs), (int16_t)(c.h >> vs) };
-                    L.num_ras[ch] = n + 1;
-                }
+            const int ch = c.c_idx > 0, hs = ch ? f.hs : 0, vs = ch ? f.vs : 0;
+            if (n_own < 1024) {
+                if (tid == 0)
+                    L.ras[ch][n_own] = ReconArea{ (int16_t)(c.x0 >> hs), (int16_t)(c.y0 >> vs), (int16_t)(c.w >> hs), (int16_t)(c.h >> vs) };
+                n_own++;
             }
-            __syncthreads();
+            group_sync<64>();
         } else if (c.kind == VVC355_RECON_PRED) {
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
             const int x = c.x0 >> hs, y = c.y0 >> vs, w = c.w >> hs, h = c.h >> vs;
-            if (tid == 0) {
-                L.bc[0] = recon_left_available(f, cx, L, c.cu_y0, x, y, 16384, c_idx);
-                L.bc[1] = recon_top_available(f, cx, L, c.cu_x0, x, y, 16384, c_idx);
-            }
-            __syncthreads();
             vvc355_intra_job j = {};
-            j.plane = f.plane[c_idx];
-            j.stride = f.stride[c_idx];
             j.x = (int16_t)x; j.y = (int16_t)y; j.w = (int16_t)w; j.h = (int16_t)h;
             j.mode = (int16_t)wide_angle_mode(c.isp_split, c_idx, w, h, c.cb_width, c.cb_height, c.mode);
             j.cb_width = c.cb_width; j.cb_height = c.cb_height;
-            j.left_avail = (int16_t)L.bc[0]; j.top_avail = (int16_t)L.bc[1];
+            j.left_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_own, c.cu_y0, x, y, 16384, c_idx, tid));
+            j.top_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_own, c.cu_x0, x, y, 16384, c_idx, tid));
             j.c_idx = (uint8_t)c_idx; j.ref_idx = c_idx ? 0 : c.ref_idx;
             j.is_mip = c.is_mip; j.mip_mode = c.mip_mode; j.mip_transposed = c.mip_transposed;
             j.isp_split = c.isp_split; j.bdpcm_flag = c.bdpcm_flag;
@@ -991,48 +1127,62 @@ __global__ __launch_bounds__(256) void recon_wavefront_kernel(const vvc355_recon
                 const bool cand_up = cx.ctb_up || y0b, cand_left = cx.ctb_left || x0b;
                 j.cand_up_left = (x0b || y0b) ? (cand_left && cand_up) : cx.ctb_up_left;
             }
-            intra_pred_body<BD, 256>(j, L.arr, L.scratch, tid);
-            __syncthreads();
+            const PX plane = c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2];
+            intra_pred_body<BD, 64>(j, plane, c_idx ? ps[1] : ps[0], arr, L.scratch[role], tid);
+            if (TILE) group_sync<64>(); else recon_sync_mem();
         } else if (c.kind == VVC355_RECON_CCLM) {
-            if (tid == 0) {
-                L.bc[0] = recon_top_available(f, cx, L, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1);
-                L.bc[1] = recon_left_available(f, cx, L, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1);
-                L.bc[2] = recon_top_available(f, cx, L, c.cu_x0, c.x0, c.y0, 1, 0) != 0;
-                L.bc[3] = recon_left_available(f, cx, L, c.cu_y0, c.x0, c.y0, 1, 0) != 0;
-            }
-            __syncthreads();
+            // the coding unit's luma (every luma command before this one) must be reconstructed
+            while (L.luma_done < (int)k)
+                __builtin_amdgcn_s_sleep(1);
+            group_sync<64>();
             vvc355_cclm_job j = {};
-            j.luma = f.plane[0]; j.cb = f.plane[1]; j.cr = f.plane[2];
-            j.luma_stride = f.stride[0]; j.cb_stride = f.stride[1]; j.cr_stride = f.stride[2];
             j.x0 = c.x0; j.y0 = c.y0; j.width = c.w; j.height = c.h;
-            j.top_avail_c = (int16_t)L.bc[0]; j.left_avail_c = (int16_t)L.bc[1];
+            j.top_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_own, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1, tid));
+            j.left_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_own, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1, tid));
             j.mode = (uint8_t)c.mode; j.hs = f.hs; j.vs = f.vs;
-            j.avail_t = (uint8_t)L.bc[2]; j.avail_l = (uint8_t)L.bc[3];
+            j.avail_t = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_luma_seen, c.cu_x0, c.x0, c.y0, 1, 0, tid)) != 0);
+            j.avail_l = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_luma_seen, c.cu_y0, c.x0, c.y0, 1, 0, tid)) != 0);
             j.collocated = f.collocated;
             j.ctu_boundary = (c.y0 & ctb_mask) == 0;
-            cclm_body<BD>(j, L.prm);
-            __syncthreads();
+            cclm_body<BD, 64>(j, pl[0], ps[0], pl[1], pl[2], ps[1], ps[2], L.prm[1], tid);
+            if (TILE) group_sync<64>(); else recon_sync_mem();
         } else {
             // RESID: itx.add_residual / add_residual_joint (vvcdsp_template.c:32,48) of the block the transform stage left in c.resid
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w, n = w * c.h;
-            uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
+            const PX dst = (c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2]).at((c.y0 >> vs) * (c_idx ? ps[1] : ps[0]) + (c.x0 >> hs));
+            const int stride = c_idx ? ps[1] : ps[0];
             const int *res = (const int *)c.resid;
             const int lw = ilog2i(w);
-            for (int i = tid; i < n; i += 256) {
-                int r = gld<int>(res + i);
-                if (c.joint & 1)
-                    r = (r * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
-                const int yy = i >> lw, xx = i & (w - 1);
-                uint8_t *row = dst + row_off(yy, f.stride[c_idx]);
-                st_px<BD>(row, xx, clip_px<BD>(ld_px<BD>(row, xx) + r));
+            for (int i = tid * 4; i < n; i += 256) {          // w >= 4: four samples of one row per lane and step
+                const int4 r4 = gld<int4>(res + i);
+                int r[4] = { r4.x, r4.y, r4.z, r4.w };
+                const int o = (i >> lw) * stride + (i & (w - 1));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (c.joint & 1)
+                        r[q] = (r[q] * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
+                    dst.st(o + q, clip_px<BD>(dst.ld(o + q) + r[q]));
+                }
             }
-            __syncthreads();
+            if (TILE) group_sync<64>(); else recon_sync_mem();
+        }
+        if (role == 0 && tid == 0)
+            L.luma_done = (int)k + 1;          // issued after the command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
+    }
+    __syncthreads();
+    if constexpr (TILE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sh = c ? 1 : 0;
+            if ((c == 0) == (role == 0))
+                recon_tile_store<BD>(tile_c[c], c ? kTileChromaP : kTileLumaP, (uint8_t *)f.plane[c], f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh,
+                                     cw0 >> sh, ch0 >> sh, tid);
         }
     }
-    // publish: every wave's stores have left the CU, then one lane releases and raises the flag
+    // publish: both waves' stores have left the CU, then one lane releases and raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1050,7 +1200,12 @@ void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *fra
     using namespace vvc355;
     if (frame_host->n_work <= 0) return;
     HIP_CHECK(hipMemsetAsync((void *)frame_host->state, 0, vvc355_recon_state_bytes(frame_host->ctb_width * frame_host->ctb_height), (hipStream_t)stream));
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD>), dim3(frame_host->n_work), dim3(256), 0, (hipStream_t)stream, frame_dev));
+    // 4:2:0 with CTUs up to 128x128 walks on LDS tiles (picture widths are multiples of 8: whole 4-sample chunks); other formats on the planes
+    const bool tile = frame_host->hs == 1 && frame_host->vs == 1 && frame_host->ctb_log2 <= 7 && frame_host->width % 8 == 0 && frame_host->height % 2 == 0;
+    if (tile)
+        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, true>), dim3(frame_host->n_work), dim3(128), 0, (hipStream_t)stream, frame_dev));
+    else
+        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, false>), dim3(frame_host->n_work), dim3(128), 0, (hipStream_t)stream, frame_dev));
     HIP_CHECK(hipGetLastError());
 }
 
