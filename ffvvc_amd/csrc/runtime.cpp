@@ -4,8 +4,14 @@ namespace vvc355 {
 
 static constexpr size_t kArenaBytes = 48u << 20;   // far above any single slot call (largest: 128x135 int16 planes)
 
+// The device ordinal the process decodes on (vvc355_set_device): HIP's current device is per-thread state, and the reference calls
+// the slots from its own worker threads (libavutil/executor.c:92-110, vvc_thread.c:647-654), which never called hipSetDevice.
+std::atomic<int> g_device{ 0 };
+
 ThreadCtx::ThreadCtx()
 {
+    device = g_device.load();
+    HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_CHECK(hipMalloc((void **)&dev, kArenaBytes));
     cap = kArenaBytes;
@@ -24,7 +30,13 @@ ThreadCtx &thread_ctx()
     return ctx;
 }
 
-SlotCall::SlotCall() : ctx_(thread_ctx()) {}
+SlotCall::SlotCall() : ctx_(thread_ctx())
+{
+    if (ctx_.device != g_device.load()) {
+        fprintf(stderr, "vvc_mi355: vvc355_set_device(%d) after this thread started issuing slot calls on device %d\n", g_device.load(), ctx_.device);
+        abort();
+    }
+}
 
 SlotCall::~SlotCall()
 {

@@ -6,6 +6,7 @@
 // Each host thread therefore owns its own stream and scratch arena; entries are re-entrant.
 #pragma once
 #include "common.hpp"
+#include <atomic>
 #include <vector>
 
 namespace vvc355 {
@@ -14,10 +15,12 @@ struct ThreadCtx {
     hipStream_t stream = nullptr;
     uint8_t *dev = nullptr;      // fixed-size device scratch arena, allocated on first use
     size_t cap = 0;
+    int device = 0;              // the ordinal this context's stream and arena live on
     ThreadCtx();
     ~ThreadCtx();
 };
 ThreadCtx &thread_ctx();
+extern std::atomic<int> g_device;
 
 // A staged host rectangle: `dev` is the device address that corresponds to the caller's host pointer.
 struct Staged {

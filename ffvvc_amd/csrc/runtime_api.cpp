@@ -11,7 +11,11 @@ int vvc355_device_count(void)
         return 0;
     return n;
 }
-void vvc355_set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
+void vvc355_set_device(int ordinal)
+{
+    HIP_CHECK(hipSetDevice(ordinal));
+    vvc355::g_device.store(ordinal);        // worker threads that first call a slot later start on this device
+}
 void *vvc355_malloc(size_t bytes)
 {
     void *p = nullptr;

@@ -32,7 +32,7 @@ extern "C" {
 /* ------------------------------------------------------------------ runtime helpers (runtime_api.cpp) */
 /* Device count / selection and plain device memory, for C hosts that keep frames resident in HBM. */
 int   vvc355_device_count(void);
-void  vvc355_set_device(int ordinal);
+void  vvc355_set_device(int ordinal);           /* process-wide: also the device of every thread that calls a slot afterwards */
 void *vvc355_malloc(size_t bytes);
 void  vvc355_free(void *dev);
 void  vvc355_upload(void *dev, const void *host, size_t bytes);

@@ -194,6 +194,10 @@ static int wide_angle_mode_mapping(int isp_split, int c_idx, int tb_width, int t
     return mode;
 }
 
+/* when set, the pass stops at command `dbg_k` of CTU `dbg_rs` (a PRED) and reports the flattened job instead of predicting */
+static _Thread_local int dbg_rs = -1, dbg_k = -1;
+static _Thread_local orc_intra_job *dbg_job;
+
 ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
 {
     const int wide = bd > 8;
@@ -247,7 +251,12 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
                         const int cand_up = lc.ctb_up_flag || y0b, cand_left = lc.ctb_left_flag || x0b;
                         j.cand_up_left = (uint8_t)((x0b || y0b) ? (cand_left && cand_up) : lc.ctb_up_left_flag);
                     }
-                    orc_intra_pred_flat(bd, &j);
+                    if (dbg_rs == rs && dbg_k == (int)k) {
+                        *dbg_job = j;
+                        return;
+                    }
+                    if (dbg_rs < 0)
+                        orc_intra_pred_flat(bd, &j);
                 } else if (c->kind == ORC_RECON_CCLM) {
                     orc_cclm_job j;
                     memset(&j, 0, sizeof(j));
@@ -261,13 +270,16 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
                     j.avail_l = left_available(&lc, c->x0, c->y0, 1, 0) != 0;
                     j.collocated = f->collocated;
                     j.ctu_boundary = (c->y0 & (ctb_size - 1)) == 0;
-                    orc_intra_cclm_pred_flat(bd, &j);
+                    if (dbg_rs < 0)
+                        orc_intra_cclm_pred_flat(bd, &j);
                 } else if (c->kind == ORC_RECON_RESID) {
                     /* itransform's tail :464-472 / add_residual_for_joint_coding_chroma :166-186: x0, y0 = tb->x0, tb->y0 (luma
                      * coordinates), w, h = tb_width, tb_height (component samples) */
                     const int c_idx = c->c_idx, hs = c_idx ? f->hs : 0, vs = c_idx ? f->vs : 0;
                     uint8_t *dst = (uint8_t *)(uintptr_t)f->plane[c_idx] + (ptrdiff_t)(c->y0 >> vs) * f->stride[c_idx] + (((ptrdiff_t)c->x0 >> hs) << wide);
                     const int *res = (const int *)(uintptr_t)c->resid;
+                    if (dbg_rs >= 0)
+                        continue;
                     if (c->joint & 1)
                         orc_add_residual_joint(bd, dst, res, c->w, c->h, f->stride[c_idx], (c->joint & 2) ? -1 : 1, (c->joint >> 2) & 1);
                     else
@@ -277,4 +289,12 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
                 }
             }
         }
+}
+
+/* the job RECON derives for PRED command k of CTU rs (availability, wide-angle mode, cand_up_left): no pixel is touched */
+ORC_API void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_intra_job *out)
+{
+    dbg_rs = rs; dbg_k = k; dbg_job = out;
+    orc_recon_frame_pass(10, f);
+    dbg_rs = dbg_k = -1;
 }

@@ -312,6 +312,7 @@ typedef struct orc_recon_frame {
     uint8_t  ctb_log2, hs, vs, wpp, collocated, pad_[3];
 } orc_recon_frame;
 void orc_recon_frame_pass(int bd, const orc_recon_frame *f);
+void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_intra_job *out);
 
 #ifdef __cplusplus
 }
