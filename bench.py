@@ -40,13 +40,15 @@ from ffvvc_amd import abi, batch, sharding  # noqa: E402
 ALF_TABLES = True              # ALF through the stage driver (job descriptors built on the device from ALFParams / APS tables); --alf-jobs: host-built jobs
 SAO_TABLES = True              # SAO through the stage driver (parameters derived on the device from per-CTB tables); --sao-jobs: host-built jobs
 DEBLOCK_JOBS = False           # deblocking through the stage driver (edge parameters derived from side tables); --deblock-jobs: host-built jobs
-AFFINE_FRAC = 0.0              # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF); profiling aid --affine-frac
+AFFINE_FRAC = 0.06             # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF on both lists); --affine-frac
+GPM_FRAC = 0.05                # fraction of the regular inter blocks coded as geometric partitions (two uni-predictions + mask blend)
+CIIP_FRAC = 0.02               # fraction of the CTUs whose coding units are combined inter / intra (inter prediction aside, planar intra + blend in RECON)
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CTB = 128
 # what the chain still lacks of BASELINE.json configs[3] (8K random-access, full in-loop filter chain)
-MISSING = ["affine (PROF) blocks: batched stage exists (vvc355_affine_batch, bench.py --affine-frac), not part of the metric's frame mix",
-           "GPM / CIIP blocks in the MC stage (slots exist; the frame mix is regular bi-prediction only)"]
+MISSING = ["per-frame upload of the decoder's side tables and parse-side work (CABAC, MV derivation) — the decoder's host side",
+           "transform blocks of the CIIP coding units (the frame's CIIP CUs carry no residual)"]
 
 TC_TABLE = [0] * 18 + [3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10, 10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45,
                        51, 57, 64, 71, 80, 89, 100, 112, 125, 141, 157, 177, 198, 222, 250, 280, 314, 352, 395]
@@ -162,8 +164,9 @@ def build_chain(lib, torch, fr):
     pitches = [fr.pitch(t) for t in rec]
     rec_ptrs = [ptr(t) for t in rec]
 
-    # CTU kinds: 80 % inter (bi-pred), 20 % intra
+    # CTU kinds: 80 % inter, 20 % intra; of the inter CTUs a few are affine and a few combined inter / intra (CIIP)
     ctu_inter = rng.random(fr.n_ctus) < 0.8
+    ctu_ciip = ctu_inter & (rng.random(fr.n_ctus) < CIIP_FRAC / 0.8)
 
     # ---------------------------------------------------------------- inter prediction: regular bi-predicted 16x16 luma sub-blocks
     # with DMVR and BDOF switched on (search, parametric refinement, 8-tap MC at the refined motion, BDOF), then their 8x8
@@ -171,13 +174,17 @@ def build_chain(lib, torch, fr):
     # border exercise the edge emulation; uniformly random references make every DMVR search run to the end (worst case).
     # optionally (--affine-frac, not part of the metric's workload) some of the inter CTUs are affine instead: 4x4 luma
     # sub-blocks, bi-predicted with PROF on both lists, chroma at the sub-block motion
-    ctu_affine = ctu_inter & (rng.random(fr.n_ctus) < AFFINE_FRAC)
+    ctu_affine = ctu_inter & ~ctu_ciip & (rng.random(fr.n_ctus) < AFFINE_FRAC)
     bs = 16
     x0, y0 = batch.block_grid(fr.width // bs * bs, fr.height // bs * bs, bs, bs)
     ctu_of = (y0 // CTB) * fr.ncx + (x0 // CTB)
     aff_blk = ctu_affine[ctu_of]
-    inter = ctu_inter[ctu_of] & ~aff_blk
+    inter = ctu_inter[ctu_of] & ~aff_blk & ~ctu_ciip[ctu_of]
+    gpm_blk = inter & (rng.random(len(x0)) < GPM_FRAC)
+    inter &= ~gpm_blk
     xa0, ya0 = x0[aff_blk], y0[aff_blk]
+    xg0, yg0 = x0[gpm_blk], y0[gpm_blk]
+    ctu_of_gpm = ctu_of[gpm_blk]
     x0, y0 = x0[inter], y0[inter]
     n_blk = len(x0)
     d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8))
@@ -235,6 +242,64 @@ def build_chain(lib, torch, fr):
     chain.append(Stage("inter_pred_chroma", f"bipred_chroma_pair_kernel<{bd}>", lambda st: lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc),
                        n_blk * 2 * (bs // 2) ** 2 * 3 * isz, writes=[rec[1], rec[2]], check=check_chroma))
 
+    if len(xg0):
+        # geometric-partition blocks: two uni-directional predictions per component, blended by a 112 x 112 weight mask the job
+        # addresses with signed steps (the reference's mirrored masks); one mask with smooth diagonal weights stands for the table
+        gy, gx = np.mgrid[0:112, 0:112]
+        gmask = np.clip((gx - gy) // 4 + 4, 0, 8).astype(np.uint8)
+        d_gmask = fr.upload(gmask)
+        n_g = len(xg0)
+        gmv = rng.integers(-24 * 16, 24 * 16 + 1, size=(n_g, 4))
+        goff = rng.integers(0, 112 - 32, size=(n_g, 2))
+        gmir = rng.integers(0, 3, size=n_g)
+        gj = []
+        for c, (w, h) in enumerate(fr.dims):
+            sh = 1 if c else 0
+            j = batch.job_array(abi.GpmJob, n_g)
+            b = j["base"]
+            b["dst"] = ptr(rec[c]) + (yg0 >> sh) * fr.pitch(rec[c]) + (xg0 >> sh) * isz
+            b["dst_stride"] = fr.pitch(rec[c])
+            for r, key in enumerate(("ref0", "ref1")):
+                b[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz
+                b[key + "_stride"] = fr.pitch(ref[r][c])
+            b["mv"] = gmv
+            b["x"], b["y"], b["w"], b["h"], b["pic_w"], b["pic_h"] = xg0 >> sh, yg0 >> sh, 16 >> sh, 16 >> sh, w, h
+            b["chroma"], b["hs"], b["vs"] = int(c > 0), 1, 1
+            first = goff[:, 1] * 112 + goff[:, 0]
+            j["step_x"], j["step_y"] = 1 << sh, 112 << sh
+            m1, m2 = gmir == 1, gmir == 2
+            j["step_x"][m1] = -(1 << sh)
+            first = np.where(m1, goff[:, 1] * 112 + 111 - goff[:, 0], first)
+            j["step_y"][m2] = -(112 << sh)
+            first = np.where(m2, (111 - goff[:, 1]) * 112 + goff[:, 0], first)
+            j["weights"] = ptr(d_gmask) + first
+            gj.append(j)
+        gpm_jobs = np.concatenate(gj)
+        d_gj = fr.upload(gpm_jobs.view(np.uint8))
+        n_gj = len(gpm_jobs)
+
+        def check_gpm(fc, orc, env):
+            orc.orc_gpm_block.argtypes = [ctypes.c_int, ctypes.POINTER(abi.GpmJob)]
+            orc.orc_gpm_block.restype = None
+            idx = np.nonzero(np.isin(np.tile(ctu_of_gpm, 3), env.picks) | (np.arange(n_gj) % 53 == 0))[0]
+            dt = np.uint8 if bd == 8 else np.uint16
+            bad = 0
+            for i in idx:
+                g = abi.GpmJob.from_buffer_copy(gpm_jobs[i].tobytes())
+                c = next(k for k, p_ in enumerate(rec_ptrs) if p_ <= g.base.dst < p_ + env.after[p_].nbytes)
+                off = int(g.base.dst) - rec_ptrs[c]
+                x_, y_ = (off % pitches[c]) // isz, off // pitches[c]
+                blk = np.zeros((g.base.h, g.base.w), dt)
+                g.base.dst, g.base.dst_stride = blk.ctypes.data, g.base.w * isz
+                g.base.ref0, g.base.ref1 = env.mirror.host_addr(g.base.ref0), env.mirror.host_addr(g.base.ref1)
+                g.weights = env.mirror.host_addr(g.weights)
+                orc.orc_gpm_block(bd, ctypes.byref(g))
+                bad += not np.array_equal(env.after[rec_ptrs[c]][y_:y_ + g.base.h, x_:x_ + g.base.w], blk)
+            return len(idx), bad
+
+        chain.append(Stage("inter_pred_gpm", f"gpm_kernel<{bd}>", lambda st: lib.vvc355_gpm_batch(st, bd, ptr(d_gj), n_gj),
+                           n_g * 384 * 3 * isz, writes=rec, check=check_gpm))
+
     if len(xa0):
         # affine CTUs: every 16x16 area = 16 luma sub-blocks of 4x4 (own motion, PROF on both lists) + its 8x8 chroma blocks
         sx, sy = np.meshgrid(np.arange(0, 16, 4), np.arange(0, 16, 4))
@@ -275,7 +340,28 @@ def build_chain(lib, torch, fr):
             lib.vvc355_affine_batch(st, bd, ptr(d_afj), n_sb)
             lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_afc), n_afc)
 
-        chain.append(Stage("inter_pred_affine_prof", f"affine_kernel<{bd}>", launch_affine, len(xa0) * (256 + 128) * 3 * isz))
+        ctu_of_aff = (ay // CTB) * fr.ncx + ax // CTB
+
+        def check_affine(fc, orc, env):
+            dt = np.uint8 if bd == 8 else np.uint16
+            idx = np.nonzero(np.isin(ctu_of_aff, env.picks))[0]
+            if len(idx) > 4096:
+                idx = idx[::len(idx) // 4096]
+            bad = 0
+            for i in idx:
+                j = abi.AffineJob.from_buffer_copy(afj[i].tobytes())
+                blk = np.zeros((4, 4), dt)
+                off = int(j.dst) - rec_ptrs[0]
+                x_, y_ = (off % pitches[0]) // isz, off // pitches[0]
+                j.dst, j.dst_stride = blk.ctypes.data, 4 * isz
+                j.ref0, j.ref1, j.diff_mv = env.mirror.host_addr(j.ref0), env.mirror.host_addr(j.ref1), env.mirror.host_addr(j.diff_mv)
+                orc.orc_affine_block(bd, ctypes.byref(j))
+                bad += not np.array_equal(env.after[rec_ptrs[0]][y_:y_ + 4, x_:x_ + 4], blk)
+            cidx = np.nonzero(np.isin(np.repeat((ya0 // CTB) * fr.ncx + xa0 // CTB, 2), env.picks))[0]
+            bad += fc.check_bipred(orc, bd, afc, cidx, env.mirror, [None, env.after[rec_ptrs[1]], env.after[rec_ptrs[2]]], rec_ptrs, pitches)
+            return len(idx) + len(cidx), bad
+
+        chain.append(Stage("inter_pred_affine_prof", f"affine_kernel<{bd}>", launch_affine, len(xa0) * (256 + 128) * 3 * isz, writes=rec, check=check_affine))
 
     # ---------------------------------------------------------------- the intra CTUs: a random partition into coding units, flattened into
     # the RECON stage driver's per-CTU command lists (tests/recon_cases.py mirrors what the parse stage leaves per CTU); their
@@ -283,7 +369,60 @@ def build_chain(lib, torch, fr):
     # the residual adds through the in-order wavefront pass further down
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import recon_cases
-    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1))
+    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1), ciip_ctu=ctu_ciip)
+
+    # the inter half of the CIIP coding units: plain bi-prediction (CIIP switches DMVR / BDOF off) of every 16x16 (chroma 8x8 or 16x16)
+    # tile into packed per-CU blocks that the RECON pass blends with the planar intra prediction
+    d_ciip = fr.upload(np.zeros(max(1, work.ciip_len), np.uint8 if bd == 8 else np.uint16))
+    cj = []
+    for (c, x, y, w, h, off, _k) in work.ciip:
+        sh = 1 if c else 0
+        wc, hc = w >> sh, h >> sh
+        for ty in range(0, hc, 16):
+            for tx in range(0, wc, 16):
+                cj.append((c, (x >> sh) + tx, (y >> sh) + ty, min(16, wc - tx), min(16, hc - ty), off + ty * wc + tx, wc))
+    cj = np.array(cj, np.int64).reshape(-1, 7)
+    n_cj = len(cj)
+    if n_cj:
+        cjobs = batch.job_array(abi.BipredJob, n_cj)
+        cc = cj[:, 0]
+        cjobs["dst"] = ptr(d_ciip) + cj[:, 5] * isz
+        cjobs["dst_stride"] = cj[:, 6] * isz
+        for r, key in enumerate(("ref0", "ref1")):
+            cjobs[key] = np.array([ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz for c in range(3)], np.int64)[cc]
+            cjobs[key + "_stride"] = np.array([fr.pitch(ref[r][c]) for c in range(3)], np.int64)[cc]
+        cmv = rng.integers(-24 * 16, 24 * 16 + 1, size=(len(work.ciip), 4))
+        # every tile of a coding unit shares its motion: index of the CU each tile came from
+        cu_of_tile = np.repeat(np.arange(len(work.ciip)), [((w >> (1 if c else 0)) + 15) // 16 * (((h >> (1 if c else 0)) + 15) // 16) for (c, x, y, w, h, off, _k) in work.ciip])
+        cjobs["mv"] = cmv[cu_of_tile // 3 * 3]            # the three components of a CU are consecutive entries
+        cjobs["x"], cjobs["y"], cjobs["w"], cjobs["h"] = cj[:, 1], cj[:, 2], cj[:, 3], cj[:, 4]
+        cjobs["pic_w"], cjobs["pic_h"] = np.array([d[0] for d in fr.dims])[cc], np.array([d[1] for d in fr.dims])[cc]
+        cjobs["chroma"], cjobs["hs"], cjobs["vs"] = (cc > 0).astype(np.int64), 1, 1
+        cl, cch = cjobs[cc == 0], cjobs[cc > 0]
+        d_cl, d_cch = fr.upload(cl.view(np.uint8)), fr.upload(cch.view(np.uint8))
+        n_cl, n_cch = len(cl), len(cch)
+
+        def launch_ciip(st):
+            lib.vvc355_bipred_batch(st, bd, ptr(d_cl), n_cl)
+            lib.vvc355_bipred_batch(st, bd, ptr(d_cch), n_cch)
+
+        def check_ciip_inter(fc, orc, env):
+            dt = np.uint8 if bd == 8 else np.uint16
+            got = env.after[ptr(d_ciip)]
+            bad = 0
+            idx = range(0, n_cj, max(1, n_cj // 400))
+            for i in idx:
+                j = abi.BipredJob.from_buffer_copy(cjobs[i].tobytes())
+                blk = np.zeros((j.h, j.w), dt)
+                first, pitch_px = (int(j.dst) - ptr(d_ciip)) // isz, j.dst_stride // isz
+                j.dst, j.dst_stride = blk.ctypes.data, j.w * isz
+                j.ref0, j.ref1 = env.mirror.host_addr(j.ref0), env.mirror.host_addr(j.ref1)
+                orc.orc_bipred_block(bd, ctypes.byref(j))
+                rows = np.stack([got[first + r * pitch_px:first + r * pitch_px + j.w] for r in range(j.h)])
+                bad += not np.array_equal(rows, blk)
+            return len(idx), bad
+
+        chain.append(Stage("inter_pred_ciip", f"bipred_kernel<{bd}, true>", launch_ciip, int(work.ciip_len) * 3 * isz, writes=[d_ciip], check=check_ciip_inter))
 
     # ---------------------------------------------------------------- inverse transform + residual add, every sample of the frame
     by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape
@@ -303,7 +442,8 @@ def build_chain(lib, torch, fr):
             ox, oy = np.meshgrid(np.arange(0, q, n), np.arange(0, q, n))
             x0 = (cx0[:, None] + qx + ox.ravel()[None, :]).ravel()
             y0 = (cy0[:, None] + qy + oy.ravel()[None, :]).ravel()
-            keep = ctu_inter[(y0 // cs) * fr.ncx + (x0 // cs)]         # the intra CTUs have their own transform blocks (below)
+            kc = (y0 // cs) * fr.ncx + (x0 // cs)
+            keep = ctu_inter[kc] & ~ctu_ciip[kc]       # the intra CTUs have their own transform blocks (below); the CIIP coding units carry no residual here
             x0, y0 = x0[keep], y0[keep]
             j = batch.job_array(abi.ItxJob, len(x0))
             lg = int(np.log2(n))
@@ -458,7 +598,7 @@ def build_chain(lib, torch, fr):
     # ---------------------------------------------------------------- RECON: the intra CTUs' coding units in decoding order (prediction from
     # what earlier blocks wrote, then the residual), CTUs released in wavefront order
     if len(work.order):
-        cmds_dev = work.bind(ptr(res))
+        cmds_dev = work.bind(ptr(res), ptr(d_ciip), isz)
         d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(work.order)
         d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8))
         d_rslice, d_rcol, d_rrow = fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)
@@ -476,7 +616,8 @@ def build_chain(lib, torch, fr):
             for p_, w_ in zip(rec_ptrs, work_p):
                 env.mirror.add(p_, w_)
             env.mirror.add(ptr(res), env.snap(res))
-            hc = work.bind(env.mirror.host_addr(ptr(res)))
+            env.mirror.add(ptr(d_ciip), env.snap(d_ciip))
+            hc = work.bind(env.mirror.host_addr(ptr(res)), env.mirror.host_addr(ptr(d_ciip)), isz)
             env.mirror.add(ptr(d_cmds), hc.view(np.uint8))
             f = fc.translate(rf, env.mirror, ("plane", "cmds", "ctus", "order", "slice_idx", "ctb_to_col_bd", "ctb_to_row_bd"))
             f.state = 0
@@ -1099,7 +1240,7 @@ def parse_args(argv=None):
     ap.add_argument("--sao-jobs", action="store_true", help="profiling aid: SAO from host-built per-CTB jobs (vvc355_sao_ctb_batch) instead of the stage driver")
     ap.add_argument("--deblock-jobs", action="store_true",
                     help="profiling aid: deblock from host-built edge jobs (vvc355_deblock_batch) instead of the stage driver")
-    ap.add_argument("--affine-frac", type=float, default=0.0, help="profiling aid: fraction of the inter CTUs that are affine (+PROF)")
+    ap.add_argument("--affine-frac", type=float, default=0.06, help="fraction of the inter CTUs that are affine (+PROF); the metric uses 0.06")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="TEST AID: replace the GPU chain by a host sleep of this many ms per step (exercises the launcher, the rendezvous, "
@@ -1219,9 +1360,11 @@ def main(argv=None):
             "data": "synthetic",
             "config": {
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
-                            f"(80 % bi-pred inter CTUs, 20 % intra; {'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
+                            f"(80 % inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
+                            f"{CIIP_FRAC:.0%} of all CTUs combined inter / intra; 20 % intra CTUs reconstructed in decoding order with LFNST / implicit MTS; "
+                            f"{'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and not AFFINE_FRAC and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
             },
             "roofline": {

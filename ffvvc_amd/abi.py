@@ -119,6 +119,7 @@ BATCH_SIGNATURES = {
     "bipred_batch":     ("v", "pipi"),
     "bipred_chroma_batch": ("v", "pipi"),
     "affine_batch":     ("v", "pipi"),
+    "gpm_batch":        ("v", "pipi"),
     "deblock_frame_pass": ("v", "pipp"),
     "sao_frame_pass":   ("v", "pipp"),
     "alf_frame_pass":   ("v", "pippp"),
@@ -270,7 +271,7 @@ class ReconFrame(ctypes.Structure):
     ]
 
 
-RECON_MARK, RECON_PRED, RECON_CCLM, RECON_RESID = 0, 1, 2, 3
+RECON_MARK, RECON_PRED, RECON_CCLM, RECON_RESID, RECON_CIIP = 0, 1, 2, 3, 4
 TU_MTS_ENABLED, TU_EXPLICIT_MTS_INTRA, TU_ISP, TU_SBT, TU_SBT_HORIZONTAL, TU_SBT_POS, TU_INTRA, TU_MIP = 1, 2, 4, 8, 16, 32, 64, 128
 ITX_DERIVE_TYPE = 1
 
@@ -288,6 +289,11 @@ class BipredJob(ctypes.Structure):
         ("bdof", ctypes.c_uint8), ("hf_idx", ctypes.c_uint8), ("vf_idx", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
         ("pred_flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 5),
     ]
+
+
+class GpmJob(ctypes.Structure):
+    """Mirror of vvc355_gpm_job (and of the oracle's orc_gpm_job)."""
+    _fields_ = [("base", BipredJob), ("weights", ctypes.c_uint64), ("step_x", ctypes.c_int32), ("step_y", ctypes.c_int32)]
 
 
 class BipredResult(ctypes.Structure):

@@ -1146,6 +1146,20 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
             j.ctu_boundary = (c.y0 & ctb_mask) == 0;
             cclm_body<BD, 64>(j, pl[0], ps[0], pl[1], pl[2], ps[1], ps[2], L.prm[1], tid);
             if (TILE) group_sync<64>(); else recon_sync_mem();
+        } else if (c.kind == VVC355_RECON_CIIP) {
+            // inter.put_ciip (vvc_inter_template.c:60) of a combined inter / intra block (pred_regular_luma / _chroma, vvc_inter.c:570-575,
+            // :632-638): the intra prediction the previous command left in the picture, weighted against the inter prediction of the
+            // batched stage (c.resid: w x h pixels, packed rows); c.joint = ciip_derive_intra_weight (:530-548)
+            const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w >> hs, n = w * (c.h >> vs);
+            const int stride = c_idx ? ps[1] : ps[0], iw = c.joint;
+            const PX dst = (c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2]).at((c.y0 >> vs) * stride + (c.x0 >> hs));
+            const uint8_t *inter = (const uint8_t *)c.resid;
+            const int lw = ilog2i(w);
+            for (int i = tid; i < n; i += 64) {
+                const int o = (i >> lw) * stride + (i & (w - 1));
+                dst.st(o, (dst.ld(o) * iw + ld_px<BD>(inter, i) * (4 - iw) + 2) >> 2);
+            }
+            if (TILE) group_sync<64>(); else recon_sync_mem();
         } else {
             // RESID: itx.add_residual / add_residual_joint (vvcdsp_template.c:32,48) of the block the transform stage left in c.resid
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w, n = w * c.h;

@@ -769,8 +769,10 @@ union BipredLdsAll {
     ToolsLds<16, 16> tools;
 };
 
+// gpm != nullptr: the two predictions are the two parts of a geometric-partition coding unit (pred_gpm_blk, vvc_inter.c:466-527:
+// luma_mc / chroma_mc per part, then inter.put_gpm with the per-sample weights of the partition's mask)
 template <int BD, bool TOOLS>
-__device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredLds &L, int lane)
+__device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredLds &L, int lane, const vvc355_gpm_job *gpm = nullptr)
 {
     if (!TOOLS && !job->chroma)
         return;                                          // contract: a chroma-only launch holds chroma jobs
@@ -862,6 +864,23 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) { v0[i] = (int16_t)v0[i]; v1[i] = (int16_t)v1[i]; }     // put[..] stores int16
+    if (gpm) {
+        // put_gpm (vvc_inter_template.c:78): (s0 w + s1 (8 - w) + offset) >> max(5, 17 - bd), w = weights[y step_y + x step_x]
+        constexpr int gsh = BD <= 12 ? 17 - BD : 5, goff = 1 << (gsh - 1);
+        const uint8_t *wt = (const uint8_t *)gpm->weights;
+        const int xg = lane & 15;
+        uint8_t *dstg = (uint8_t *)job->dst;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int y = 2 * ((lane >> 4) + 4 * (i >> 1)) + (i & 1);
+            if (xg >= w || y >= h)
+                continue;
+            const int wg = gld<uint8_t>(wt + y * gpm->step_y + xg * gpm->step_x);
+            const int p = (v0[i] * wg + v1[i] * (8 - wg) + goff) >> gsh;
+            gst_at<typename Px<BD>::type>(dstg, (uint32_t)(__mul24(y, job->dst_stride) + xg * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
+        }
+        return;
+    }
     if (TOOLS && bdof) {
         bdof_wave<BD>(job, L, lane, w, h, v0, v1, ox, oy, fx, fy, rc);
         return;
@@ -894,6 +913,25 @@ __global__ __launch_bounds__(256) void bipred_kernel(const vvc355_bipred_job *__
     // fields through the pointer would be a vector load with a full memory round trip at every point of use.
     const vvc355_bipred_job job_copy = load_uniform(jobs + ji);
     bipred_one<BD, TOOLS>(&job_copy, *(BipredLds *)&lds_all[wave], lane);      // without TOOLS only win / tmpT are touched
+}
+
+// Geometric-partition blocks: one wave per (<= 16x16 tile of a) part pair.  The job's base is a bi-prediction job without tools
+// whose two references are the two parts' reference pictures.
+template <int BD>
+__global__ __launch_bounds__(256) void gpm_kernel(const vvc355_gpm_job *__restrict__ jobs, int n_jobs)
+{
+    __shared__ __attribute__((aligned(16))) BipredLdsLight lds_all[4];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ji = xcd_chunked(blockIdx.x, gridDim.x) * 4 + wave;
+    if (ji >= n_jobs)
+        return;
+    const vvc355_gpm_job job = load_uniform(jobs + ji);
+    vvc355_bipred_job base = job.base;
+    base.pred_flag = 3; base.dmvr = 0; base.bdof = 0; base.weight_flag = 0; base.rec = 0;
+    if (base.chroma)
+        bipred_one<BD, false>(&base, *(BipredLds *)&lds_all[wave], lane, &job);
+    else
+        bipred_one<BD, true>(&base, *(BipredLds *)&lds_all[wave], lane, &job);
 }
 
 // Chroma launch: one wave per PAIR of consecutive jobs.  When the two are the Cb and Cr blocks of one sub-block (same
@@ -1020,6 +1058,14 @@ extern "C" void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_jo
     using namespace vvc355;
     if (n_jobs <= 0) return;
     VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((bipred_kernel<BD, true>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
+    HIP_CHECK(hipGetLastError());
+}
+
+extern "C" void vvc355_gpm_batch(void *stream, int bd, const vvc355_gpm_job *jobs_dev, int n_jobs)
+{
+    using namespace vvc355;
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((gpm_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs));
     HIP_CHECK(hipGetLastError());
 }
 

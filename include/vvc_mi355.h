@@ -455,6 +455,24 @@ void vvc355_bipred_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev
 /* the same for a launch in which EVERY job has chroma != 0 (jobs that do not are skipped): smaller LDS footprint */
 void vvc355_bipred_chroma_batch(void *stream, int bd, const vvc355_bipred_job *jobs_dev, int n_jobs);
 
+/*
+ * One (<= 16x16 tile of a) geometric-partition coding unit, what pred_gpm_blk (vvc_inter.c:466-527) does per component: the two
+ * parts' uni-directional predictions (luma_mc / chroma_mc: put[..] at each part's motion, edge emulation to the picture) blended
+ * by inter.put_gpm with the partition's per-sample weights.
+ *   base      as vvc355_bipred_job: ref0 / mv[0..1] = part 0's reference picture and motion, ref1 / mv[2..3] = part 1's; dst, geometry,
+ *             chroma / hs / vs, hf_idx / vf_idx; dmvr, bdof, weights and rec are ignored
+ *   weights   DEVICE address of the weight of the tile's sample (0, 0) inside the mask the reference selects
+ *             (&ff_vvc_gpm_weights[weights_idx][...] with the mirror handling of :488-497, advanced to the tile), values 0..8
+ *   step_x, step_y   address steps per sample / per row in that mask (+-1 << hs, +-(112 << vs))
+ */
+typedef struct vvc355_gpm_job {
+    vvc355_bipred_job base;
+    uint64_t weights;
+    int32_t  step_x, step_y;
+} vvc355_gpm_job;
+
+void vvc355_gpm_batch(void *stream, int bd, const vvc355_gpm_job *jobs_dev, int n_jobs);
+
 /* ------------------------------------------------------------------ affine sub-blocks with PROF (affine.hip) */
 
 /*
@@ -672,6 +690,9 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  *   PRED   intra.intra_pred(lc, x0, y0, w, h, c_idx)                                             (luma coordinates, like the slot)
  *   CCLM   intra.intra_cclm_pred(lc, x0, y0, w, h)
  *   RESID  itx.add_residual / add_residual_joint of transform block (tb->x0, tb->y0 luma coordinates; w, h = tb_width, tb_height)
+ *   CIIP   inter.put_ciip after the PRED of a combined inter / intra coding unit (ff_vvc_predict_ciip, vvc_inter.c:915; luma
+ *          coordinates): resid = the inter prediction of the batched stage (w x h pixels of the component, packed rows),
+ *          joint = the intra weight ciip_derive_intra_weight (:530-548) gives
  * Neighbour availability is derived on the device from the running list of reconstructed areas exactly as
  * ff_vvc_get_top_available / _left_available do (:574-648), ctb_up / ctb_left flags from the slice and tile tables
  * (ff_vvc_decode_neighbour, vvc_ctu.c:2468), the wide-angle mapping (:693) from the command's mode.
@@ -679,7 +700,7 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  * not depend on neighbours, so only prediction + add is serialised.  Transform blocks of coding units that are not intra-coded
  * are added by the batched stage itself (dst != 0) before this pass; their CTUs need no commands.
  */
-enum { VVC355_RECON_MARK = 0, VVC355_RECON_PRED = 1, VVC355_RECON_CCLM = 2, VVC355_RECON_RESID = 3 };
+enum { VVC355_RECON_MARK = 0, VVC355_RECON_PRED = 1, VVC355_RECON_CCLM = 2, VVC355_RECON_RESID = 3, VVC355_RECON_CIIP = 4 };
 typedef struct vvc355_recon_cmd {
     uint64_t resid;            /* RESID: DEVICE int32[w * h] */
     int16_t  x0, y0, w, h;

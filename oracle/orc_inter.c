@@ -514,6 +514,36 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
 }
 
 
+/* ------------------------------------------------------------------ callers: one (tile of a) geometric-partition coding unit
+ *
+ * pred_gpm_blk (vvc_inter.c:466-527) for one component: luma_mc / chroma_mc of each part into an int16 plane (put[..] at the part's
+ * motion, edge emulation to the picture), then put_gpm with the mask weights the job addresses.
+ */
+ORC_API void orc_gpm_block(int bd, const orc_gpm_job *g)
+{
+    const orc_bipred_job *job = &g->base;
+    const int wide = bd > 8;
+    const int w = job->w, h = job->h, chroma = job->chroma;
+    const uint8_t *ref[2] = { (const uint8_t *)(uintptr_t)job->ref0, (const uint8_t *)(uintptr_t)job->ref1 };
+    const ptrdiff_t rstride[2] = { job->ref0_stride, job->ref1_stride };
+    static _Thread_local int16_t tmpbuf[2][(ORC_PB + 4) * ORC_PB];
+    static _Thread_local uint8_t emu[EMU_STRIDE * (ORC_PB + 8) * 2];
+    const int before = chroma ? 1 : 3, after = chroma ? 2 : 4, extra = before + after;
+    const int shx = 4 + (chroma ? job->hs : 0), shy = 4 + (chroma ? job->vs : 0);
+    for (int i = 0; i < 2; i++) {
+        const int mvx = job->mv[2 * i], mvy = job->mv[2 * i + 1];
+        const int mx = chroma ? (mvx & ((1 << shx) - 1)) << (1 - job->hs) : mvx & 15;
+        const int my = chroma ? (mvy & ((1 << shy) - 1)) << (1 - job->vs) : mvy & 15;
+        const int ox = job->x + (mvx >> shx), oy = job->y + (mvy >> shy);
+        const int8_t *hf = chroma ? orc_tab_inter_chroma_filters + (job->hf_idx * 32 + mx) * 4 : orc_tab_inter_luma_filters + (job->hf_idx * 16 + mx) * 8;
+        const int8_t *vf = chroma ? orc_tab_inter_chroma_filters + (job->vf_idx * 32 + my) * 4 : orc_tab_inter_luma_filters + (job->vf_idx * 16 + my) * 8;
+        emu_window(wide, emu, ref[i], rstride[i], ox - before, oy - before, w + extra, h + extra, 0, 0, job->pic_w - 1, job->pic_h - 1);
+        const uint8_t *src = emu + (((ptrdiff_t)before * EMU_STRIDE + before) << wide);
+        orc_put(bd, chroma, !!my, !!mx, tmpbuf[i], src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
+    }
+    orc_put_gpm(bd, (uint8_t *)(uintptr_t)job->dst, job->dst_stride, w, h, tmpbuf[0], tmpbuf[1], (const uint8_t *)(uintptr_t)g->weights, g->step_x, g->step_y);
+}
+
 /* ------------------------------------------------------------------ callers: one 4x4 luma sub-block of an affine CU
  *
  * luma_prof_uni (vvc_inter.c:369-406) and luma_prof_bi (:408-447), as pred_affine_blk (:864-897) calls them per sub-block:

@@ -272,6 +272,13 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
                     j.ctu_boundary = (c->y0 & (ctb_size - 1)) == 0;
                     if (dbg_rs < 0)
                         orc_intra_cclm_pred_flat(bd, &j);
+                } else if (c->kind == ORC_RECON_CIIP) {
+                    /* put_ciip (vvc_inter_template.c:60) as pred_regular_luma / _chroma call it after the intra prediction (vvc_inter.c:570-575) */
+                    const int c_idx = c->c_idx, hs = c_idx ? f->hs : 0, vs = c_idx ? f->vs : 0;
+                    uint8_t *dst = (uint8_t *)(uintptr_t)f->plane[c_idx] + (ptrdiff_t)(c->y0 >> vs) * f->stride[c_idx] + (((ptrdiff_t)c->x0 >> hs) << wide);
+                    if (dbg_rs >= 0)
+                        continue;
+                    orc_put_ciip(bd, dst, f->stride[c_idx], c->w >> hs, c->h >> vs, (const uint8_t *)(uintptr_t)c->resid, (ptrdiff_t)(c->w >> hs) << wide, c->joint);
                 } else if (c->kind == ORC_RECON_RESID) {
                     /* itransform's tail :464-472 / add_residual_for_joint_coding_chroma :166-186: x0, y0 = tb->x0, tb->y0 (luma
                      * coordinates), w, h = tb_width, tb_height (component samples) */

@@ -116,6 +116,12 @@ typedef struct orc_bipred_result {
     int32_t bdof, min_sad, searched, pad_;
 } orc_bipred_result;
 void orc_bipred_block(int bd, const orc_bipred_job *job);
+typedef struct orc_gpm_job {
+    orc_bipred_job base;
+    uint64_t weights;
+    int32_t  step_x, step_y;
+} orc_gpm_job;
+void orc_gpm_block(int bd, const orc_gpm_job *job);
 
 /* ---- one 4x4 luma sub-block of an affine coding unit incl. PROF (orc_inter.c, "luma_prof_uni / luma_prof_bi") ----
  * Same layout as vvc355_affine_job of include/vvc_mi355.h, with host addresses. */
@@ -293,7 +299,7 @@ int  orc_ilfnst_transform(int *coeffs, int w, int h, int pred_mode_intra, int lf
 int  orc_derive_transform_type(int flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h);
 
 /* ---- RECON of a picture from per-CTU command lists (orc_recon.c, "ff_vvc_reconstruct"); layouts as in include/vvc_mi355.h ---- */
-enum { ORC_RECON_MARK = 0, ORC_RECON_PRED = 1, ORC_RECON_CCLM = 2, ORC_RECON_RESID = 3 };
+enum { ORC_RECON_MARK = 0, ORC_RECON_PRED = 1, ORC_RECON_CCLM = 2, ORC_RECON_RESID = 3, ORC_RECON_CIIP = 4 };
 typedef struct orc_recon_cmd {
     uint64_t resid;
     int16_t  x0, y0, w, h;

@@ -16,7 +16,7 @@ class ReconWork:
     cmds["resid"] as ELEMENT offsets until `bind(base_address)` turns them into addresses."""
 
     def __init__(self, rng, width, height, ctb_log2=7, hs=1, vs=1, intra_frac=1.0, intra_ctu=None, cclm_frac=0.2, coded_p=0.7,
-                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True):
+                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True, ciip_frac=0.0, ciip_ctu=None):
         self.width, self.height, self.ctb_log2, self.hs, self.vs = width, height, ctb_log2, hs, vs
         ctb = 1 << ctb_log2
         self.ncx, self.ncy = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
@@ -33,15 +33,39 @@ class ReconWork:
         cmds, ctus = [], np.zeros(n_ctb, CTU)
         self.resid_len = 0
         self.tbs = []                     # (c_idx, x0, y0 luma, w, h component samples, element offset): what the transform stage must fill
+        self.ciip = []                    # (c_idx, x0, y0, w, h luma units, pixel offset into the inter-prediction storage, command index)
+        self.ciip_len = 0
+        self.ciip_frac = ciip_frac
         for rs in range(n_ctb):
             rx, ry = rs % self.ncx, rs // self.ncx
             first = len(cmds)
             ctu_intra = intra_frac if intra_ctu is None else (1.0 if intra_ctu[rs] else 0.0)
             leaves = []
-            _split(rng, rx * ctb, ry * ctb, ctb, ctb, width, height, min_cu, leaves, *split)
+            whole_ciip = ciip_ctu is not None and bool(ciip_ctu[rs])
+            if whole_ciip:          # a CTU of 32x32 combined inter / intra coding units
+                leaves = [(x, y, 32, 32) for y in range(ry * ctb, min(ry * ctb + ctb, height - 31), 32) for x in range(rx * ctb, min(rx * ctb + ctb, width - 31), 32)]
+            else:
+                _split(rng, rx * ctb, ry * ctb, ctb, ctb, width, height, min_cu, leaves, *split)
             any_intra = False
             cu_cmds = []
             for (x, y, w, h) in leaves:
+                if whole_ciip or rng.random() >= ctu_intra and self.ciip_frac and w * h >= 64 and w < 128 and h < 128 and rng.random() < self.ciip_frac:
+                    # combined inter / intra (ff_vvc_predict_ciip): planar intra prediction of each component, blended with the inter
+                    # prediction the batched stage left aside; the area is recorded like any reconstructed coding unit
+                    any_intra = True
+                    cu = (x, y, w, h)
+                    iw = int(rng.integers(1, 4))
+                    for c in range(3):
+                        if c and (w >> self.hs) <= 2:
+                            continue
+                        cu_cmds.append(self._cmd(abi.RECON_PRED, c, x, y, w, h, *cu, mode=0))
+                        off = self.ciip_len
+                        self.ciip_len += (w >> (self.hs if c else 0)) * (h >> (self.vs if c else 0))
+                        self.ciip.append((c, x, y, w, h, off, len(cmds) + len(cu_cmds)))
+                        cu_cmds.append(self._cmd(abi.RECON_CIIP, c, x, y, w, h, *cu, resid=off, joint=iw))
+                    cu_cmds.append(self._cmd(abi.RECON_MARK, 0, x, y, w, h, *cu))
+                    cu_cmds.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, *cu))
+                    continue
                 if rng.random() >= ctu_intra:
                     # not intra-coded: prediction and residual come from the batched stages, the walk only records the area
                     cu_cmds.append(self._cmd(abi.RECON_MARK, 0, x, y, w, h, x, y, w, h))
@@ -110,11 +134,14 @@ class ReconWork:
                     out.append(self._cmd(abi.RECON_RESID, 2, x, y, cw, chh, *cu, resid=out[-1][0], joint=1 | (2 * int(rng.integers(0, 2))) | (4 * int(rng.integers(0, 2)))))
                     break
 
-    def bind(self, base):
-        """Command array with residual element offsets turned into addresses at `base` (int32 storage)."""
+    def bind(self, base, ciip_base=0, isz=2):
+        """Command array with residual element offsets turned into addresses at `base` (int32 storage), CIIP pixel offsets into
+        addresses at `ciip_base` (pixels of `isz` bytes)."""
         c = self.cmds.copy()
         is_res = c["kind"] == abi.RECON_RESID
         c["resid"][is_res] = base + c["resid"][is_res] * 4
+        is_ci = c["kind"] == abi.RECON_CIIP
+        c["resid"][is_ci] = ciip_base + c["resid"][is_ci] * isz
         return c
 
     def frame(self, planes, strides, cmds_ptr, ctus_ptr, order_ptr, state_ptr, slice_ptr, col_ptr, row_ptr, wpp=0, collocated=0):

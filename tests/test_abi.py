@@ -13,11 +13,14 @@ def declared_symbols():
     for path in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = open(path).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names |= set(re.findall(r"\b(vvc355_\w+|ff_vvc_dsp_init_mi355)\s*\(", text))
+        names |= set(re.findall(r"\b(vvc355_\w+|ff_vvc_dsp_init_mi355\w*)\s*\(", text))
     return names
 
 
-HOST_SYMBOLS = {"ff_vvc_dsp_init_mi355", "vvc355_dsp_count_slots", "vvc355_dsp_table_selftest"}
+# exported by the C host shim (libvvc_mi355_host.so): the table installers and the context flattening of include/vvc_mi355_ctx.h
+HOST_SYMBOLS = {"ff_vvc_dsp_init_mi355", "ff_vvc_dsp_init_mi355_ctx", "vvc355_dsp_count_slots", "vvc355_dsp_table_selftest",
+                "vvc355_ctx_flatten_cclm", "vvc355_ctx_flatten_intra_pred", "vvc355_ctx_flatten_lmcs_scale", "vvc355_ctx_left_available",
+                "vvc355_ctx_top_available"}
 
 
 def test_library_exports_every_declared_symbol():
@@ -41,4 +44,6 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.BipredJob) == 96 and ctypes.sizeof(abi.BipredResult) == 32
     assert ctypes.sizeof(abi.AffineJob) == 88
     assert ctypes.sizeof(abi.MvField) == 24 and ctypes.sizeof(abi.BsFrame) == 312
+    assert ctypes.sizeof(abi.ReconCmd) == 40 and ctypes.sizeof(abi.ReconCtu) == 8 and ctypes.sizeof(abi.ReconFrame) == 120
+    assert ctypes.sizeof(abi.LfnstJob) == 32 and ctypes.sizeof(abi.GpmJob) == 112 and ctypes.sizeof(abi.ItxJob) == 48
     assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136

@@ -12,21 +12,22 @@ from ffvvc_amd import abi, batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
-def test_bipred_frame(dev, orc, bd):
+@pytest.mark.parametrize("bd,fmt", [(8, (1, 1)), (10, (1, 1)), (12, (1, 1)), (10, (1, 0)), (10, (0, 0)), (8, (0, 0)), (12, (1, 0))])
+def test_bipred_frame(dev, orc, bd, fmt):
     bc.bind_oracle(orc)
-    rng = np.random.default_rng(0x5EED0800 + bd)
+    hs, vs = fmt                      # 4:2:0, 4:2:2 (hs only) and 4:4:4: the chroma motion fraction and block size follow (vvc_inter.c:209-212)
+    rng = np.random.default_rng(0x5EED0800 + bd + 64 * (1 - hs) + 128 * (1 - vs))
     pw, ph = 208, 144
     isz = 1 if bd == 8 else 2
-    base = [bc.smooth_picture(rng, ph, pw, bd), bc.smooth_picture(rng, ph // 2, pw // 2, bd), bc.smooth_picture(rng, ph // 2, pw // 2, bd)]
+    base = [bc.smooth_picture(rng, ph, pw, bd), bc.smooth_picture(rng, ph >> vs, pw >> hs, bd), bc.smooth_picture(rng, ph >> vs, pw >> hs, bd)]
     # reference 1 = reference 0 displaced by a small whole-sample motion plus noise: the search has something to find
     refs = [[p.copy() for p in base], []]
     for c, p in enumerate(base):
         noise = rng.integers(-3, 4, size=p.shape)
         noise[:, :3 * p.shape[1] // 4] = 0        # left three quarters: an exact displaced copy (zero-cost matches exist)
-        q = bc.shifted(p, 2 >> (c > 0), -2 >> (c > 0)).astype(np.int64) + noise
+        q = bc.shifted(p, 2 >> (hs if c else 0), -2 >> (vs if c else 0)).astype(np.int64) + noise
         refs[1].append(np.clip(q, 0, (1 << bd) - 1).astype(p.dtype))
-    dims = [(pw, ph), (pw // 2, ph // 2), (pw // 2, ph // 2)]
+    dims = [(pw, ph), (pw >> hs, ph >> vs), (pw >> hs, ph >> vs)]
     blocks = bc.random_blocks(rng, pw, ph)
     n = len(blocks)
 
@@ -69,12 +70,12 @@ def test_bipred_frame(dev, orc, bd):
         wf = int(rng.random() < 0.3 and not dmvr)
         for c in range(3):
             j = abi.BipredJob()
-            sh = 1 if c else 0
-            j.x, j.y, j.w, j.h = x >> sh, y >> sh, w >> sh, h >> sh
+            sx, sy = (hs, vs) if c else (0, 0)
+            j.x, j.y, j.w, j.h = x >> sx, y >> sy, w >> sx, h >> sy
             j.pic_w, j.pic_h = dims[c]
             for k, v in enumerate(mv0 + mv1):
                 j.mv[k] = v
-            j.chroma, j.hs, j.vs = int(c > 0), 1, 1
+            j.chroma, j.hs, j.vs = int(c > 0), hs, vs
             j.dmvr, j.bdof, j.weight_flag, j.pred_flag = dmvr, bdof, wf, pred_flag
             j.hf_idx = j.vf_idx = int(rng.integers(0, 2)) if c == 0 else 0
             if c:
@@ -124,10 +125,10 @@ def test_bipred_frame(dev, orc, bd):
         bad = np.argwhere(got != want[c])
         if len(bad):
             # which blocks, with which tools: the pattern of a failure says more than its first sample
-            sh = 1 if c else 0
+            sx, sy = (hs, vs) if c else (0, 0)
             rows = []
             for i, (x, y, w, h) in enumerate(blocks):
-                m = got[y >> sh:(y + h) >> sh, x >> sh:(x + w) >> sh] != want[c][y >> sh:(y + h) >> sh, x >> sh:(x + w) >> sh]
+                m = got[y >> sy:(y + h) >> sy, x >> sx:(x + w) >> sx] != want[c][y >> sy:(y + h) >> sy, x >> sx:(x + w) >> sx]
                 if m.any():
                     j = host_jobs[3 * i][0]
                     ys_, xs_ = np.nonzero(m)
@@ -140,3 +141,67 @@ def test_bipred_frame(dev, orc, bd):
     bd_in = np.array([hj[0].bdof for hj in host_jobs[::3]], bool)
     assert np.any(exp_rec[bd_in, 4] == 1) and np.any((exp_rec[:, 4] == 0) & bd_in & dm)
     assert np.any(np.any(exp_rec[:, :4] != np.array([[*hj[0].mv] for hj in host_jobs[::3]]), axis=1))
+
+
+@pytest.mark.parametrize("bd,fmt", [(10, (1, 1)), (8, (0, 0)), (12, (1, 0))])
+def test_gpm_batch(dev, orc, bd, fmt):
+    """Geometric-partition blocks (pred_gpm_blk, vvc_inter.c:466-527): two uni-directional predictions blended by a per-sample
+    weight mask with signed steps (mirrored masks), luma and chroma, blocks at and beyond the picture edge."""
+    orc.orc_gpm_block.argtypes = [ctypes.c_int, ctypes.POINTER(abi.GpmJob)]
+    orc.orc_gpm_block.restype = None
+    rng = np.random.default_rng(0x5EED0900 + bd)
+    hs, vs = fmt
+    pw, ph = 176, 112
+    isz = 1 if bd == 8 else 2
+    dims = [(pw, ph), (pw >> hs, ph >> vs), (pw >> hs, ph >> vs)]
+    refs = [[bc.smooth_picture(rng, d[1], d[0], bd) for d in dims] for _ in range(2)]
+    mask = rng.integers(0, 9, size=(112, 112)).astype(np.uint8)           # stands for one ff_vvc_gpm_weights[] mask (values 0..8)
+    want = [np.full((d[1], d[0]), 0x33, refs[0][0].dtype) for d in dims]
+    d_out = [batch.DeviceBuffer.from_host(w_) for w_ in want]
+    d_refs = [[batch.DeviceBuffer.from_host(p) for p in r] for r in refs]
+    d_mask = batch.DeviceBuffer.from_host(mask)
+    jobs = []
+    for y in range(0, ph - 15, 16):
+        for x in range(0, pw - 15, 16):
+            w, h = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
+            mv = [int(v) for v in rng.integers(-300, 301, size=4)]
+            if rng.random() < 0.2:
+                mv = [int(v) for v in rng.integers(-4000, 4001, size=4)]
+            mirror = int(rng.integers(0, 3))
+            off_x, off_y = int(rng.integers(0, 112 - 64)), int(rng.integers(0, 112 - 64))
+            for c in range(3):
+                sx, sy = (hs, vs) if c else (0, 0)
+                g = abi.GpmJob()
+                j = g.base
+                j.x, j.y, j.w, j.h = x >> sx, y >> sy, w >> sx, h >> sy
+                j.pic_w, j.pic_h = dims[c]
+                for k, v in enumerate(mv):
+                    j.mv[k] = v
+                j.chroma, j.hs, j.vs = int(c > 0), hs, vs
+                j.dst_stride = j.ref0_stride = j.ref1_stride = dims[c][0] * isz
+                g.step_x, g.step_y = 1 << sx, 112 << sy
+                first = off_y * 112 + off_x
+                if mirror == 1:
+                    g.step_x, first = -g.step_x, off_y * 112 + 111 - off_x
+                elif mirror == 2:
+                    g.step_y, first = -g.step_y, (111 - off_y) * 112 + off_x
+                jobs.append((g, c, first))
+    arr = (abi.GpmJob * len(jobs))()
+    for i, (g, c, first) in enumerate(jobs):
+        hg = abi.GpmJob.from_buffer_copy(g)
+        hg.base.dst = P(want[c], hg.base.y * dims[c][0] + hg.base.x)
+        hg.base.ref0, hg.base.ref1 = P(refs[0][c]), P(refs[1][c])
+        hg.weights = mask.ctypes.data + first
+        orc.orc_gpm_block(bd, ctypes.byref(hg))
+        g.base.dst = d_out[c].ptr + (g.base.y * dims[c][0] + g.base.x) * isz
+        g.base.ref0, g.base.ref1 = d_refs[0][c].ptr, d_refs[1][c].ptr
+        g.weights = d_mask.ptr + first
+        arr[i] = g
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_gpm_batch(None, bd, d_jobs.ptr, len(jobs))
+    dev.vvc355_stream_sync(None)
+    for c in range(3):
+        got = d_out[c].to_host(want[c].dtype, want[c].shape)
+        bad = np.argwhere(got != want[c])
+        assert len(bad) == 0, f"component {c}: {len(bad)} samples differ, first at {bad[0].tolist()}"
+    assert np.any(want[0] != 0x33)

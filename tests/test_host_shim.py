@@ -113,7 +113,7 @@ def test_context_taking_slots_through_the_table(orc, bd):
         fc.lmcs.chroma_scale_coeff[i] = 1800 + 37 * i
     lc = cm.VVCLocalContext()
     lc.fc = ctypes.pointer(fc)
-    lc.ctb_left_flag = lc.ctb_up_flag = 1
+    lc.ctb_left_flag, lc.ctb_up_flag = 1, 0            # the CTU at (128, 0): a left neighbour, nothing above (picture top)
     lc.end_of_tiles_x = w
     # the CTU at (128, 0) with its left half reconstructed: areas of 32x32 coding units in decoding order
     for ch in range(2):

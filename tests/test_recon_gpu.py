@@ -24,17 +24,18 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
     dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
     planes = [bc.smooth_picture(rng, ph, pw, bd, scale=16) for (pw, ph) in dims]
     resid = rng.integers(-(1 << (bd - 3)), 1 << (bd - 3), size=max(1, work.resid_len)).astype(np.int32)
+    inter = rng.integers(0, 1 << bd, size=max(1, work.ciip_len)).astype(planes[0].dtype)          # inter predictions of the CIIP coding units
     # oracle on host copies
     want = [p.copy() for p in planes]
-    hc = work.bind(resid.ctypes.data)
+    hc = work.bind(resid.ctypes.data, inter.ctypes.data, isz)
     hf = work.frame([P(p) for p in want], [d[0] * isz for d in dims], hc.ctypes.data, work.ctus.ctypes.data, work.order.ctypes.data, 0,
                     work.slice_idx.ctypes.data, work.col_bd.ctypes.data, work.row_bd.ctypes.data, wpp=kw.get("n_slices", 1) > 2, collocated=int(rng.integers(0, 2)))
     orc.orc_recon_frame_pass(bd, ctypes.byref(hf))
     # device
     pitched = [batch.to_pitched(p) for p in planes]
     d_planes = [batch.DeviceBuffer.from_host(p) for p in pitched]
-    d_res = batch.DeviceBuffer.from_host(resid)
-    dcmd = work.bind(d_res.ptr)
+    d_res, d_inter = batch.DeviceBuffer.from_host(resid), batch.DeviceBuffer.from_host(inter)
+    dcmd = work.bind(d_res.ptr, d_inter.ptr, isz)
     d_cmds, d_ctus, d_order = batch.DeviceBuffer.from_host(dcmd.view(np.uint8)), batch.DeviceBuffer.from_host(work.ctus.view(np.uint8)), batch.DeviceBuffer.from_host(work.order if len(work.order) else np.zeros(1, np.int32))
     d_state = batch.DeviceBuffer(dev.vvc355_recon_state_bytes(work.ncx * work.ncy))
     d_slice, d_col, d_row = batch.DeviceBuffer.from_host(work.slice_idx), batch.DeviceBuffer.from_host(work.col_bd), batch.DeviceBuffer.from_host(work.row_bd)
@@ -72,7 +73,7 @@ def test_recon_mixed_picture(dev, orc, bd):
     """Inter and intra coding units mixed, whole CTUs without intra work among them (those are skipped by the scheduler)."""
     rng = np.random.default_rng(0x5EED0E77)
     intra_ctu = rng.random(12 * 7) < 0.4
-    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_frac=0.5, intra_ctu=None)
-    assert 0 < len(work.order) <= 12 * 7
+    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_frac=0.5, intra_ctu=None, ciip_frac=0.3)
+    assert 0 < len(work.order) <= 12 * 7 and (work.cmds["kind"] == abi.RECON_CIIP).sum() > 20
     work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_ctu=intra_ctu)
     assert 0 < len(work.order) < 12 * 7
