@@ -83,6 +83,7 @@ class Frame:
         self.keep = []
         self.dims = [(width, height), (width // 2, height // 2), (width // 2, height // 2)]
         self.host = {}        # data_ptr -> host copy of every uploaded table (what the `verified` leg mirrors for the oracle)
+        self.torch_of = {}
         self.noise = False
 
     def picture(self, c, pad, like=None, shift=(0, 0), sigma=2.0):
@@ -133,6 +134,7 @@ class Frame:
         t = self.torch.from_numpy(host).cuda()
         self.keep.append(t)
         self.host[t.data_ptr()] = host
+        self.torch_of[t.data_ptr()] = t
         return t
 
     def pitch(self, t):
@@ -1007,20 +1009,25 @@ def recorded_valu(root, stage_name):
     return None if d is None else {k: d[k] for k in ("valu_insts_per_wave", "valu_issue_utilisation", "by_tool_valu_per_wave")}
 
 
-def cpu_baseline(root, fr, budget_s):
-    """The CPU oracle (oracle/liborc.so, a scalar C restatement: kind "port") timed on ONE host core over a bounded sample
-    of the same per-CTU work: one inter CTU's worth of every stage, repeated; reported in frames/s of the same chain."""
+def cpu_chain(root, bd):
+    """One inter CTU's worth of every stage through the CPU oracle (oracle/liborc.so, a scalar C restatement): the unit of work the
+    CPU baseline repeats.  Returns a callable; nothing here touches the GPU or torch."""
     import subprocess
     so = os.path.join(root, "oracle", "liborc.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
     orc = ctypes.CDLL(so)
     abi.bind(orc, "orc_", {k: v for k, v in abi.SLOT_SIGNATURES.items() if hasattr(orc, "orc_" + k)})
-    bd = fr.bd
     rng = np.random.default_rng(7)
     dt = np.uint8 if bd == 8 else np.uint16
     isz = np.dtype(dt).itemsize
-    A = lambda a, o=0: a.ctypes.data + o * a.itemsize  # noqa: E731
+    addr = {}
+
+    def A(a, o=0):                      # cached: numpy's .ctypes accessor costs about a microsecond, as much as a small oracle call
+        k = id(a)
+        if k not in addr:
+            addr[k] = (a, a.ctypes.data)
+        return addr[k][1] + o * a.itemsize
     luma = rng.integers(0, 1 << bd, size=(CTB + 16, CTB + 32)).astype(dt)
     ls = luma.shape[1]
     dst = np.zeros((CTB, CTB), dt)
@@ -1037,6 +1044,7 @@ def cpu_baseline(root, fr, budget_s):
     z4 = np.zeros(4, np.uint8); l3 = np.full(4, 3, np.uint8)
     borders = np.zeros(4, np.int32)
     res = {s: rng.integers(-(1 << 12), 1 << 12, size=(s, s)).astype(np.int32) for s in (4, 8, 16, 32, 64)}
+    work = {k: np.empty_like(v) for k, v in res.items()}
     off = 8 * ls + 8
     saosrc = rng.integers(0, 1 << bd, size=(CTB + 2, 320 // isz)).astype(dt)
 
@@ -1080,8 +1088,9 @@ def cpu_baseline(root, fr, budget_s):
         # inverse transform + residual add: the luma and chroma TB mix of build_chain
         for (s, cnt) in ((64, 1), (32, 4 + 2), (16, 16 + 8), (8, 64 + 32), (4, 128)):
             for _ in range(cnt):
-                r = res[s].copy()
-                lg = int(np.log2(s))
+                r = work[s]
+                r[:] = res[s]
+                lg = s.bit_length() - 1
                 orc.orc_dequant(A(r), lg, lg, 0, 0, min(s, 12) - 1, min(s, 12) - 1, 30, 0, 1, bd, 15, None, 1, -1)
                 orc.orc_itx(0, 0, lg, lg, A(r), min(s, 12), min(s, 12), 15, bd)
                 orc.orc_add_residual(bd, A(dst), A(r), s, s, CTB * isz)
@@ -1105,22 +1114,80 @@ def cpu_baseline(root, fr, budget_s):
             orc.orc_alf_filter_chroma(bd, A(dst), CTB * isz, A(luma, off), ls * isz, 64, 64, A(ch_c), A(ch_cl), 62)
             orc.orc_alf_filter_cc(bd, A(dst), CTB * isz, A(luma, off), ls * isz, 64, 64, 1, 1, A(cc_c), CTB - 4)
 
+    one_ctu.keep = (bp_ref, bp_rec, bp_jobs, bs_t, bs_f, dst)      # the job structs hold raw addresses into these
+    return one_ctu
+
+
+def cpu_time_chain(one_ctu, seconds):
+    """Repeat the chain for about `seconds`; returns (CTUs done, elapsed)."""
     one_ctu()
-    t_0 = time.perf_counter()
-    one_ctu()
-    per = time.perf_counter() - t_0
-    n_ctus = int(max(4, min(fr.n_ctus, budget_s / max(per, 1e-6))))
-    t_0 = time.perf_counter()
-    for _ in range(n_ctus):
+    n, t_0 = 0, time.perf_counter()
+    while True:
         one_ctu()
-    dt_s = time.perf_counter() - t_0
+        n += 1
+        dt_s = time.perf_counter() - t_0
+        if dt_s >= seconds:
+            return n, dt_s
+
+
+def cpu_worker_main(args):
+    """``--cpu-worker SECONDS``: one host thread of the all-core CPU baseline.  A fresh process that never imports torch and never
+    makes a HIP call; prints {"ctus": n, "s": elapsed}."""
+    n, dt_s = cpu_time_chain(cpu_chain(ROOT, args.bd), args.cpu_worker)
+    print(json.dumps({"ctus": n, "s": dt_s}), flush=True)
+    return 0
+
+
+def host_cpu():
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "?")
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def cpu_baseline(root, fr, budget_s, max_workers=0):
+    """The CPU oracle (kind "port") timed on the host: first on ONE core, then on every core this process may run on (one worker
+    process per core, each repeating whole CTUs — one CTU per task, no shared state), over a bounded sample of the same per-CTU work:
+    one inter CTU's worth of every stage.  `value` is the all-core figure in frames/s of the same chain; `one_core` sits beside it."""
+    import subprocess
+    model, nproc, usable = host_cpu()
+    one = cpu_chain(root, fr.bd)
+    n1, dt1 = cpu_time_chain(one, min(6.0, budget_s / 2))
+    one_core = (n1 / fr.n_ctus) / dt1
+    cores = usable if max_workers <= 0 else min(usable, max_workers)
+    t_each = max(2.0, budget_s - dt1 - 2.0)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t_each:.2f}", "--bd", str(fr.bd)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True) for _ in range(cores)]
+    rate, n_all, t_max = 0.0, 0, 0.0
+    for pr in procs:
+        o, _ = pr.communicate(timeout=t_each * 4 + 120)
+        if pr.returncode != 0:
+            raise RuntimeError("CPU baseline worker failed")
+        d = json.loads(o.strip().splitlines()[-1])
+        rate += d["ctus"] / d["s"]
+        n_all += d["ctus"]
+        t_max = max(t_max, d["s"])
     return {
-        "value": (n_ctus / fr.n_ctus) / dt_s,
+        "value": rate / fr.n_ctus,
         "unit": "frames/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": f"{n_ctus} of {fr.n_ctus} CTUs (128x128, {bd}-bit 4:2:0), each through the same stage chain as one inter CTU "
-                  f"(bi-prediction with DMVR + BDOF, dequant + itx + residual, LMCS, deblock, SAO, ALF) in {dt_s:.2f} s on one host core",
+        "one_core": one_core,
+        "host": {"cpu_model": model, "nproc": nproc, "usable": usable},
+        "sample": f"{n_all} CTUs in {t_max:.1f} s on {cores} worker processes ({n1} CTUs in {dt1:.1f} s on one core first); a frame is "
+                  f"{fr.n_ctus} CTUs (128x128, {fr.bd}-bit 4:2:0); each CTU goes through the same stage chain as one inter CTU (bi-prediction "
+                  f"with DMVR + BDOF, dequant + itx + residual, LMCS, boundary strengths, deblock, SAO, ALF + CC-ALF)",
+        "reference_c": "not built here (needs configure-generated headers); BASELINE.md section 2's single-thread rates of the reference's "
+                       "C path (Xeon 2.1 GHz, no assembler) sum to about 2.8 s per 8K inter frame, i.e. about 0.36 frames/s per core; the "
+                       "oracle is a plain restatement and runs the same functions 1-8x slower (profiles/r02_oracle_rates_container.json)",
     }
 
 
@@ -1229,11 +1296,15 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--bd", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="independent frames processed concurrently per step (one HIP stream each); 1 = latency of a single frame")
+    ap.add_argument("--with-upload", action="store_true", help="additionally time the steps with every per-frame descriptor copied from pinned host memory first")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
     ap.add_argument("--noise", action="store_true", help="profiling aid: uniformly random reference samples and dense residuals (checkasm-style) "
                                                          "instead of picture-like content: every DMVR search runs to the end, deblocking mostly early-outs")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="rough budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough wall-clock budget of the CPU baseline leg (one core first, then all cores)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-core CPU baseline (0 = one per usable core)")
+    ap.add_argument("--cpu-worker", type=float, default=None, help="INTERNAL: run as one CPU-baseline worker for this many seconds (no GPU, no torch)")
     ap.add_argument("--mc-tools", type=int, default=3, help="profiling aid: 1 = DMVR, 2 = BDOF, 3 = both (the metric's workload)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph in the timed region (per-stage times then come from an untimed pass)")
     ap.add_argument("--alf-jobs", action="store_true", help="profiling aid: ALF from host-built per-CTB jobs (three batch launches, CC-ALF without the outermost CTB ring) instead of the stage driver")
@@ -1251,6 +1322,8 @@ def parse_args(argv=None):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.cpu_worker is not None:
+        return cpu_worker_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
     global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES
@@ -1270,26 +1343,42 @@ def main(argv=None):
     lib = abi.load()
     lib.vvc355_set_device(local_rank)
 
-    frame = Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank)
-    frame.noise = args.noise
-    chain = build_chain(lib, torch, frame)
-    if args.only:
-        chain = [st for st in chain if st.name in args.only.split(",")]
-    stream = torch.cuda.current_stream().cuda_stream
+    # F independent frames in flight per step, each on its own HIP stream — how a frame-parallel decoder keeps the device busy (the
+    # reference decodes several frames at once: frame threads, libavcodec/vvc/vvc_thread.c; SURVEY 8d sizes batches in frames in
+    # flight).  The in-order intra pass of one frame (a dependent chain, few waves) then overlaps the other frames' throughput
+    # kernels.  --frames-in-flight 1 measures the latency of one frame instead.
+    n_ff = max(1, args.frames_in_flight)
+    frames, chains, streams = [], [], []
+    for i in range(n_ff):
+        fr_i = Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank + 977 * i)
+        fr_i.noise = args.noise
+        ch_i = build_chain(lib, torch, fr_i)
+        if args.only:
+            ch_i = [st for st in ch_i if st.name in args.only.split(",")]
+        frames.append(fr_i)
+        chains.append(ch_i)
+        streams.append(torch.cuda.Stream())
+    frame, chain = frames[0], chains[0]
+    torch.cuda.synchronize()
 
     # events are created before the timed region; inside it they are only recorded
     pool = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chain] for _ in range(args.steps)]
 
-    def run_step(events=None, step=0, only=None):
-        for i, st in enumerate(chain):
-            if events is not None and (only is None or st.name == only):
+    def run_frame(f, events=None, step=0, only=None):
+        sh = streams[f].cuda_stream
+        for i, st in enumerate(chains[f]):
+            if f == 0 and events is not None and (only is None or st.name == only):
                 e0, e1 = pool[step][i]
-                e0.record()
-                st.launch(stream)
-                e1.record()
+                e0.record(streams[0])
+                st.launch(sh)
+                e1.record(streams[0])
                 events.setdefault(st.name, []).append((e0, e1))
             else:
-                st.launch(stream)
+                st.launch(sh)
+
+    def run_step(events=None, step=0, only=None):
+        for f in range(n_ff):
+            run_frame(f, events, step, only)
 
     def barrier():
         sharding.barrier(dist, world, torch.cuda.synchronize)
@@ -1297,19 +1386,23 @@ def main(argv=None):
     for _ in range(args.warmup):
         run_step()
     barrier()
-    # Untimed pass with HIP events around every stage: the per-stage breakdown (`stages`) and which stage dominates.  The timed
-    # region then carries events around that one stage only (the roofline figure) — 38 event records per step are not free.
+    # Untimed pass of ONE frame alone with HIP events around every stage: the per-stage breakdown (`stages`), the latency of a frame
+    # and which stage dominates.  The timed region then carries events around that one stage only (the roofline figure).
     events = {}
+    t_lat = time.perf_counter()
     for k in range(args.steps):
-        run_step(events, k)
+        run_frame(0, events, k)
     torch.cuda.synchronize()
+    frame_latency_ms = (time.perf_counter() - t_lat) / args.steps * 1e3
     breakdown = {name: float(np.mean([a.elapsed_time(b) for a, b in ev])) for name, ev in events.items()}
-    dom_name = max(breakdown, key=breakdown.get)
+    # the in-order intra pass is a latency-bound dependent chain on a few hundred waves; with several frames in flight it runs
+    # beside the other frames' kernels, so the kernel that bounds throughput is the largest of the batched stages
+    throughput_stages = {k: v for k, v in breakdown.items() if not (n_ff > 1 and k == "intra_recon_wavefront")} or breakdown
+    dom_name = max(throughput_stages, key=throughput_stages.get)
     barrier()
     events = {}
     if args.graph:
-        # the timed region replays one captured hipGraph per step (what a decoder integration would do: one launch per frame
-        # instead of 19); no events inside it
+        # the timed region replays one captured hipGraph per step (one launch per frame instead of ~25); no events inside it
         gs = lib.vvc355_stream_create()
         lib.vvc355_graph_begin(gs)
         for st in chain:
@@ -1318,6 +1411,7 @@ def main(argv=None):
         lib.vvc355_graph_launch(gexec, gs)
         lib.vvc355_stream_sync(gs)
         barrier()
+        n_ff = 1
         t0 = time.perf_counter()
         for k in range(args.steps):
             lib.vvc355_graph_launch(gexec, gs)
@@ -1331,6 +1425,31 @@ def main(argv=None):
         elapsed = time.perf_counter() - t0
     barrier()
     elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cpu")
+
+    # second figure: the same steps with every per-frame descriptor (job arrays, side tables, command lists) copied from pinned host
+    # memory at the start of each frame — what a decoder that builds them on the host pays over PCIe (the coefficient levels, which
+    # are generated on the device here, are not included: their size is reported)
+    upload = None
+    if args.with_upload and not args.graph:
+        pinned = [[(frames[f].torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in frames[f].host.items()] for f in range(n_ff)]
+        up_bytes = sum(h_.nbytes for h_ in frames[0].host.values())
+
+        def run_step_upload():
+            for f in range(n_ff):
+                with torch.cuda.stream(streams[f]):
+                    for dst_t, src_t in pinned[f]:
+                        dst_t.copy_(src_t, non_blocking=True)
+                run_frame(f)
+        run_step_upload()
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            run_step_upload()
+        torch.cuda.synchronize()
+        el_up = sharding.max_over_ranks(dist, torch, world, time.perf_counter() - t1, "cpu")
+        upload = {"value": world * n_ff * args.steps / el_up, "unit": "frames/s", "descriptor_bytes_per_frame": int(up_bytes),
+                  "ms_per_step": el_up / args.steps * 1e3,
+                  "not_included": "coefficient levels (int32 in the reference ABI, generated on the device here)"}
 
     if rank == 0:
         stage_ms = dict(breakdown)
@@ -1347,12 +1466,15 @@ def main(argv=None):
             "metric": "decoded frames/sec (4K/8K 10-bit VVC) per GPU",
             "parity": "device output == in-repo CPU oracle on this frame (`verified`: sampled CTUs per prediction / transform stage, whole picture "
                       "for the loop-filter stages); the oracle itself is unpinned (no FATE bitstreams or reference build in this environment)",
-            "value": world * args.steps / elapsed,
+            "value": world * n_ff * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "frames_per_step": n_ff,
+            "frame_latency_ms": frame_latency_ms,          # one frame alone, stage after stage (untimed pass): latency, not throughput
+            "incl_descriptor_upload": upload,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1360,12 +1482,12 @@ def main(argv=None):
             "data": "synthetic",
             "config": {
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
-                            f"(80 % inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
+                            f"({n_ff} independent frame(s) in flight per step, one HIP stream each; per frame 80 % inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
                             f"{CIIP_FRAC:.0%} of all CTUs combined inter / intra; 20 % intra CTUs reconstructed in decoding order with LFNST / implicit MTS; "
                             f"{'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
                 "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
-                "parallelism": f"{world} independent frame stream(s), one per GPU, no collective",
+                "parallelism": f"{world} independent frame stream(s), one per GPU, no collective; {n_ff} frame(s) in flight per GPU",
             },
             "roofline": {
                 "stage": dom.name,
@@ -1377,6 +1499,8 @@ def main(argv=None):
                 "frac": achieved / HBM_PEAK_GBS,
                 "ms_per_launch": stage_ms[dom.name],
                 "algorithmic_bytes_per_launch": dom.algorithmic_bytes,
+                "note": ("dominant = the batched stage with the largest launch time; the in-order intra pass (intra_recon_wavefront) is a latency-bound "
+                         "dependent chain on a few hundred waves that overlaps the other frames in flight — see stages / frame_latency_ms") if n_ff > 1 else "",
                 "traffic": None,                          # PMC counters are collected in separate rocprofv3 passes: see `recorded`
                 # NOT measured in this run: counter passes of an earlier run of the same command, committed under profiles/
                 "recorded": {"source": "profiles/pmc_traffic.json, profiles/mc_valu.json (rocprofv3 --pmc passes, see profiles/README.md)",
@@ -1400,7 +1524,7 @@ def main(argv=None):
         if not args.no_verify and not args.only:
             out["verified"] = verify_step(lib, torch, frame, chain, args.verify_ctus)
         if not args.no_cpu_baseline and world == 1:       # a reported baseline, timed once: rank 0 of the single-GPU run
-            out["cpu_baseline"] = cpu_baseline(ROOT, frame, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(ROOT, frame, args.cpu_seconds, args.cpu_workers)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

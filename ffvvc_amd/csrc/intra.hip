@@ -14,9 +14,21 @@
 
 namespace vvc355 {
 
-#define VVC355_TABLE(type, name, count) __device__ static const type i_tab_##name[count]
+#define VVC355_TABLE(type, name, count) __device__ static const type i_tab_##name[count] __attribute__((aligned(16)))
 #include "tables.inc"
 #undef VVC355_TABLE
+
+#ifdef VVC355_RECON_PROF
+// profiling build only (tools/dbg): 100 MHz wall-clock ticks per phase, summed over all CTUs by lane 0 of each wave
+__device__ unsigned long long vvc355_recon_prof[64];
+#define RPROF_NOW() wall_clock64()
+#define RPROF_ADD(slot, t0) do { atomicAdd(&vvc355_recon_prof[slot], tid == 0 ? (unsigned long long)(wall_clock64() - (t0)) : 0ull); } while (0)
+#define RPROF_INC(slot) do { atomicAdd(&vvc355_recon_prof[slot], tid == 0 ? 1ull : 0ull); } while (0)
+#else
+#define RPROF_NOW() 0ull
+#define RPROF_ADD(slot, t0) do { (void)(t0); } while (0)
+#define RPROF_INC(slot) do { } while (0)
+#endif
 
 static constexpr int kEdgeOrg = 64 + 3;          // MAX_TB_SIZE + 3
 static constexpr int kEdgeLen = 6 * 64 + 5;
@@ -38,7 +50,14 @@ __host__ __device__ inline int intra_inv_angle(int angle)
     const int r = (16384 + a / 2) / a;
     return angle < 0 ? -r : r;
 }
-__host__ __device__ inline int ilog2i(int v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+__host__ __device__ inline int ilog2i(int v)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return v <= 1 ? 0 : 31 - __clz(v);
+#else
+    int r = 0; while (v > 1) { v >>= 1; r++; } return r;
+#endif
+}
 __host__ __device__ inline int intra_nscale(int w, int h, int mode)
 {
     if (mode == 0 || mode == 1 || mode == 18 || mode == 50)
@@ -81,12 +100,52 @@ template <int BD> struct GPix {
     __device__ __forceinline__ void st(ptrdiff_t off, int v) const { st_px<BD>(p, off, v); }
     __device__ __forceinline__ GPix at(ptrdiff_t off) const { return GPix{ p + off * (ptrdiff_t)sizeof(typename Px<BD>::type) }; }
 };
+// The rows above a CTU as the RECON stage driver keeps them in LDS (kApr rows of their own, reaching one CTU to the right for the
+// above-right references), or nothing.  `on`: this block's top edge is the CTU's top edge, so every sample above it comes from here.
+static constexpr int kApr = 4;          // apron rows above / columns to the left (reference line 3 is line -4)
+struct StripRef {
+    const uint16_t *p;
+    int pitch, x0s;
+    bool on;
+    __device__ __forceinline__ int at(int x_abs, int r) const { return p[(kApr + r) * pitch + x_abs - x0s]; }
+};
+static constexpr StripRef kNoStrip = { nullptr, 0, 0, false };
+
 struct LPix {
     uint16_t *p;
     int base;
     __device__ __forceinline__ int ld(int off) const { return p[base + off]; }
     __device__ __forceinline__ void st(int off, int v) const { p[base + off] = (uint16_t)v; }
     __device__ __forceinline__ LPix at(int off) const { return LPix{ p, base + off }; }
+};
+
+// component c's accessor out of three, chosen field by field (a conditional expression on the whole struct would be taken through
+// memory — scratch — and lose the pointer's address space)
+template <int BD> __device__ __forceinline__ GPix<BD> pick3(int c, GPix<BD> a, GPix<BD> b, GPix<BD> d) { return GPix<BD>{ c == 0 ? a.p : c == 1 ? b.p : d.p }; }
+__device__ __forceinline__ LPix pick3(int c, LPix a, LPix b, LPix d) { return LPix{ a.p, c == 0 ? a.base : c == 1 ? b.base : d.base }; }      // one LDS array
+__device__ __forceinline__ StripRef pick3(int c, StripRef a, StripRef b, StripRef d)
+{
+    return StripRef{ a.p + (c == 0 ? 0 : c == 1 ? (int)(b.p - a.p) : (int)(d.p - a.p)), c == 0 ? a.pitch : c == 1 ? b.pitch : d.pitch, c == 0 ? a.x0s : c == 1 ? b.x0s : d.x0s, false };
+}
+
+// constant tables the predictors index per sample: straight from the device's constant arrays (batched kernels: many waves hide the
+// latency), or from a copy the RECON stage driver keeps in LDS (one wave walks a dependent chain there: every global round trip
+// is on the critical path)
+struct IntraTabsLds {
+    uint32_t luma_filter[64];            // fC[32] then fG[32], four int8 taps per entry
+    uint8_t mip4[1024], mip8[1024], mip16[2688];
+};
+struct GTabs {
+    __device__ __forceinline__ uint32_t filt4(int e) const { uint32_t d; __builtin_memcpy(&d, i_tab_intra_luma_filter + e * 4, 4); return d; }
+    __device__ __forceinline__ const uint8_t *mip(int size_id) const
+    {
+        return size_id == 0 ? i_tab_mip_matrix_4x4 : size_id == 1 ? i_tab_mip_matrix_8x8 : i_tab_mip_matrix_16x16;
+    }
+};
+struct LTabs {
+    const IntraTabsLds *t;
+    __device__ __forceinline__ uint32_t filt4(int e) const { return t->luma_filter[e]; }
+    __device__ __forceinline__ const uint8_t *mip(int size_id) const { return size_id == 0 ? t->mip4 : size_id == 1 ? t->mip8 : t->mip16; }
 };
 
 // ------------------------------------------------------------------------------------------------ leaf predictors
@@ -110,18 +169,38 @@ __device__ void pred_planar(int tid, PX src, int stride, R top, R left, int w, i
     }
 }
 
+// sum of v over the group's lanes, returned to all of them.  Groups inside a wave: prefix sums along the rows of 16 (DPP), then the
+// row totals through readlane; the workgroup: an LDS accumulator.
+template <int NT> __device__ __forceinline__ int group_sum(int v, int tid, int *scratch)
+{
+    if (NT <= 64) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+        const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+        const int r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+        if (NT == 64)
+            return r0 + r1 + r2 + r3;
+        return (__lane_id() & 32) ? r2 + r3 : r0 + r1;
+    } else {
+        if (tid == 0) *scratch = 0;
+        __syncthreads();
+        if (v) atomicAdd(scratch, v);
+        __syncthreads();
+        return *scratch;
+    }
+}
+
 template <int BD, int NT, typename R, typename PX>
 __device__ void pred_dc(int tid, PX src, int stride, R top, R left, int w, int h, int *scratch)
 {
-    if (tid == 0) {
-        const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
-        int sum = 0;
-        if (w >= h) for (int i = 0; i < w; i++) sum += top(i);
-        if (w <= h) for (int i = 0; i < h; i++) sum += left(i);
-        *scratch = (sum + (int)(offset >> 1)) >> ilog2i((int)offset);
-    }
-    group_sync<NT>();
-    const int dc = *scratch, w4 = (w + 3) & ~3;          // stores cover whole groups of 4 (:856)
+    int part = 0;
+    if (w >= h) for (int i = tid; i < w; i += NT) part += top(i);
+    if (w <= h) for (int i = tid; i < h; i += NT) part += left(i);
+    const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
+    const int dc = (group_sum<NT>(part, tid, scratch) + (int)(offset >> 1)) >> ilog2i((int)offset);
+    const int w4 = (w + 3) & ~3;                          // stores cover whole groups of 4 (:856)
     const int lw4 = ilog2i(w4);
     for (int i = tid; i < w4 * h; i += NT) {
         const int y = i >> lw4, x = i & (w4 - 1);
@@ -140,21 +219,21 @@ __device__ void pred_vh(int tid, PX src, int stride, R ref, int w, int h, bool v
     }
 }
 
-template <int BD, typename R>
-__device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx, int filter_flag)
+template <int BD, typename R, typename TB>
+__device__ __forceinline__ int angular_sample(R ref, int i, int fact, int c_idx, int filter_flag, TB tabs)
 {
     if (!fact && (c_idx || !filter_flag))
         return ref(i + 1);
     if (!c_idx) {
-        const int8_t *f = i_tab_intra_luma_filter + (filter_flag * 32 + fact) * 4;
-        return clip_px<BD>((ref(i) * f[0] + ref(i + 1) * f[1] + ref(i + 2) * f[2] + ref(i + 3) * f[3] + 32) >> 6);
+        const int f = (int)tabs.filt4(filter_flag * 32 + fact);
+        return clip_px<BD>((ref(i) * (int)(int8_t)f + ref(i + 1) * (int)(int8_t)(f >> 8) + ref(i + 2) * (int)(int8_t)(f >> 16) + ref(i + 3) * (f >> 24) + 32) >> 6);
     }
     return ((32 - fact) * ref(i + 1) + fact * ref(i + 2) + 16) >> 5;
 }
 
-template <int BD, int NT, typename R, typename PX>
+template <int BD, int NT, typename R, typename PX, typename TB = GTabs>
 __device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, int h, bool vertical,
-                             int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc)
+                             int c_idx, int mode, int ref_idx, int filter_flag, int need_pdpc, TB tabs = TB{})
 {
     const int angle = intra_pred_angle(mode);
     int inv = 0, nscale = 0;
@@ -168,8 +247,8 @@ __device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, 
         const int along = vertical ? x : y, across = vertical ? y : x;
         const int pos = (1 + ref_idx + across) * angle;
         const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
-        int pred = vertical ? angular_sample<BD>(top, base + along + idx, fact, c_idx, filter_flag)
-                            : angular_sample<BD>(left, base + along + idx, fact, c_idx, filter_flag);
+        int pred = vertical ? angular_sample<BD>(top, base + along + idx, fact, c_idx, filter_flag, tabs)
+                            : angular_sample<BD>(left, base + along + idx, fact, c_idx, filter_flag, tabs);
         if (need_pdpc) {
             if (vertical) {
                 if (x < min(w, 3 << nscale)) {
@@ -186,15 +265,13 @@ __device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, 
 }
 
 // MIP (:708-824).  `red` = 16 ints of LDS scratch.
-template <int BD, int NT, typename R, typename PX>
-__device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int h, int mode_id, int transposed, int *red)
+template <int BD, int NT, typename R, typename PX, typename TB = GTabs>
+__device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int h, int mode_id, int transposed, int *red, TB tabs = TB{})
 {
     const int size_id = (w == 4 && h == 4) ? 0 : ((w == 4 || h == 4) || (w == 8 && h == 8)) ? 1 : 2;
     const int bsize = size_id == 0 ? 2 : 4, psize = size_id == 2 ? 8 : 4;
     const int in_size = 2 * bsize - (size_id == 2);
-    const uint8_t *matrix = size_id == 0 ? i_tab_mip_matrix_4x4 + mode_id * 16 * 4
-                          : size_id == 1 ? i_tab_mip_matrix_8x8 + mode_id * 16 * 8
-                                         : i_tab_mip_matrix_16x16 + mode_id * 64 * 7;
+    const uint8_t *matrix = tabs.mip(size_id) + mode_id * (size_id == 0 ? 16 * 4 : size_id == 1 ? 16 * 8 : 64 * 7);
     const int up_h = w / psize, up_v = h / psize;
     group_sync<NT>();
     for (int k = tid; k < 2 * bsize; k += NT) {
@@ -282,8 +359,9 @@ __global__ __launch_bounds__(256) void intra_leaf_kernel(LeafArgs a)
 // workgroup; both with wave-level synchronisation only.  NT = 256: one workgroup per block.
 // the whole slot for one block, executed by a group of NT lanes (tid = lane's index in the group); arr = four edge arrays in LDS
 // plane = accessor of the component plane's sample (0, 0); stride in pixels
-template <int BD, int NT, typename PX>
-__device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_px, uint16_t (*arr)[kEdgeLen], int *scratch, int tid)
+template <int BD, int NT, typename PX, typename TB = GTabs>
+__device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_px, uint16_t (*arr)[kEdgeLen], int *scratch, int tid,
+                                const StripRef sr = kNoStrip, TB tabs = TB{})
 {
     const int stride = stride_px;
     const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx;
@@ -307,14 +385,17 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         utop = top_size = refw; uleft = left_size = refh;
     }
     const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
+    const int prof_o = c_idx ? 32 : 0; (void)prof_o;
+    unsigned long long t_ph = RPROF_NOW();
+#define RPHASE(slot) do { RPROF_ADD((slot) + prof_o, t_ph); t_ph = RPROF_NOW(); } while (0)
 #define GETP(x, y) src.ld((x) + __mul24(stride, (y)))
     for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
-    for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)GETP(i, ref_line);
+    for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)(sr.on ? sr.at(j.x + i, ref_line) : GETP(i, ref_line));
     // the corner samples -1 .. ref_line (at most four) go out with the edge loads, on the last lanes of the group
     if (j.cand_up_left && tid >= NT + ref_line) {
         const int i = tid - NT;
-        left[i] = (uint16_t)GETP(ref_line, i);
-        top[i] = (uint16_t)GETP(i, ref_line);
+        left[i] = (uint16_t)(sr.on ? sr.at(j.x + ref_line, i) : GETP(ref_line, i));
+        top[i] = (uint16_t)(sr.on ? sr.at(j.x + i, ref_line) : GETP(i, ref_line));
     }
     group_sync<NT>();
     if (!j.cand_up_left && tid < -ref_line) {
@@ -328,6 +409,7 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         for (int i = la + tid; i < uleft; i += NT) left[i] = lfill;
     }
     group_sync<NT>();
+    RPHASE(22);
     if (rff && smooth) {                                  // ref_filter (:450)
         const int keep_last = left_size == uleft;
         if (tid == 0)
@@ -369,14 +451,16 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         }
     }
 
+    RPHASE(23);
     LRef T{ top }, L{ left };
-    if (is_mip)          pred_mip<BD, NT>(tid, src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch);
+    if (is_mip)          pred_mip<BD, NT>(tid, src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch, tabs);
     else if (mode == 0)  pred_planar<BD, NT>(tid, src, stride, T, L, w, h);
     else if (mode == 1)  pred_dc<BD, NT>(tid, src, stride, T, L, w, h, scratch);
     else if (mode == 50) pred_vh<BD, NT>(tid, src, stride, T, w, h, true);
     else if (mode == 18) pred_vh<BD, NT>(tid, src, stride, L, w, h, false);
-    else                 pred_angular<BD, NT>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc);
+    else                 pred_angular<BD, NT>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc, tabs);
 
+    RPHASE(24);
     if (need_pdpc && !is_mip && (mode == 0 || mode == 1 || mode == 50 || mode == 18)) {      // :654-682
         group_sync<NT>();
         const int scale = (ilog2i(w) + ilog2i(h) - 2) >> 2;
@@ -397,6 +481,8 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
             src.st(x + __mul24(stride, y), clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
         }
     }
+    RPHASE(25);
+#undef RPHASE
 #undef GETP
 }
 
@@ -565,7 +651,7 @@ void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
 namespace vvc355 {
 
 template <int BD, typename PX>
-__device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, PX luma, int s, int cx, int cy)
+__device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, PX luma, int s, int cx, int cy, const StripRef sl = kNoStrip)
 {
     const int hs = j.hs, vs = j.vs;
     const int o = (j.y0 + (cy << vs)) * s + j.x0 + (cx << hs);
@@ -577,7 +663,8 @@ __device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, PX luma, i
         return (L(lx, 0) + 2 * L(0, 0) + L(1, 0) + 2) >> 2;
     if (j.collocated) {
         const int ty = (cy || j.avail_t) ? -1 : 0;
-        return (L(lx, 0) + L(0, ty) + 4 * L(0, 0) + L(1, 0) + L(0, 1) + 4) >> 3;
+        const int above = (sl.on && !cy && ty) ? sl.at(j.x0 + (cx << hs), -1) : L(0, ty);
+        return (L(lx, 0) + above + 4 * L(0, 0) + L(1, 0) + L(0, 1) + 4) >> 3;
     }
     return (L(lx, 0) + L(lx, 1) + 2 * L(0, 0) + 2 * L(0, 1) + L(1, 0) + L(1, 1) + 4) >> 3;
 #undef L
@@ -586,7 +673,8 @@ __device__ __forceinline__ int cclm_ds_luma(const vvc355_cclm_job &j, PX luma, i
 // the whole slot for one block, executed by the workgroup; prm = six ints in LDS (a[2], b[2], k[2])
 // luma / cb / cr = accessors of the planes' sample (0, 0), strides in pixels (the job's addresses and strides are not used)
 template <int BD, int NT, typename PX>
-__device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX cr, int cs0, int cs1, int *prm, int tid)
+__device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX cr, int cs0, int cs1, int *prm, int tid,
+                          const StripRef sl = kNoStrip, const StripRef sb = kNoStrip, const StripRef sr = kNoStrip)
 {
     const int hs = j.hs, vs = j.vs;
     const int x = j.x0 >> hs, y = j.y0 >> vs, w = j.width >> hs, h = j.height >> vs;
@@ -595,15 +683,19 @@ __device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX c
     const int cs[2] = { cs0, cs1 };
 
     if (!avail_t && !avail_l) {
-        for (int i = tid; i < 2 * w * h; i += NT) {
-            const int c = i / (w * h), r = i - c * w * h, yy = r / w, xx = r - yy * w;
-            cpl[c].st((y + yy) * cs[c] + x + xx, 1 << (BD - 1));
+        const int lw0 = ilog2(w);
+        for (int i = tid; i < w * h; i += NT) {
+            const int yy = i >> lw0, xx = i & (w - 1);
+            cb.st((y + yy) * cs0 + x + xx, 1 << (BD - 1));
+            cr.st((y + yy) * cs1 + x + xx, 1 << (BD - 1));
         }
         return;
     }
-    if (tid == 0) {
+    // cclm_get_params (:29-349): the (at most four) selected neighbour positions are fetched by four lanes of the group's first
+    // wave — luma down-sampled the way the position asks for, the two chroma samples beside it — and the min / max pairing and the
+    // line fit run on wave-uniform values (readlane), so nothing is indexed dynamically in registers
+    if (tid < 64) {
         int a[2] = { 0, 0 }, b[2] = { 1 << (BD - 1), 1 << (BD - 1) }, k[2] = { 0, 0 };
-        int cnt[2] = { 0, 0 }, pos[2][4], have = 0;
         const int lt = j.mode == 81;
         const int is4 = !avail_t || !avail_l || !lt;
         int num[2];
@@ -613,98 +705,115 @@ __device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX c
             num[1] = (avail_l && j.mode == 82) ? min(h + min(w, h), (int)j.left_avail_c) : 0;
         }
         if (num[0] || num[1]) {
-            have = 1;
+            int cnt[2], start[2], step[2];
             for (int i = 0; i < 2; i++) {
-                const int start = num[i] >> (2 + is4), step = max(1, num[i] >> (1 + is4));
+                start[i] = num[i] >> (2 + is4);
+                step[i] = max(1, num[i] >> (1 + is4));
                 cnt[i] = min(num[i], (1 + is4) << 1);
-                for (int c = 0; c < 4; c++)
-                    pos[i][c] = start + c * step;
             }
-        }
-        if (have) {
-            int sel[3][8];
-            for (int c = 0; c < 3; c++) for (int i = 0; i < 8; i++) sel[c][i] = 0;
+            const int total = cnt[0] + cnt[1];
+            // lane q holds entry q of the reference's four-entry arrays (two samples: entries 1, 0, 1, 0)
+            const int q = tid & 3, si = total == 2 ? (~q & 1) : q;
+            const bool from_top = si < cnt[0];
+            const int i = from_top ? si : si - cnt[0];
+            int s0 = 0, s1 = 0, s2 = 0;
             const int lo = j.y0 * ls + j.x0;
 #define LP(off) luma.ld((int)(off))
-            for (int i = 0; i < cnt[0]; i++) {
-                if (!hs && !vs) { sel[0][i] = LP(lo - avail_t * ls + pos[0][i]); continue; }
-                const int xx = pos[0][i] << hs;
-                const int has_left = xx || avail_l;
-                if (vs && !j.ctu_boundary) {
-                    const int o = lo - 2 * ls + xx;
-                    const int l = has_left ? LP(o - 1) : LP(o);
-                    if (j.collocated)
-                        sel[0][i] = (LP(o - ls) + l + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
-                    else {
-                        const int l1 = has_left ? LP(o - 1 + ls) : LP(o + ls);
-                        sel[0][i] = (l + l1 + 2 * (LP(o) + LP(o + ls)) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+            if (si < total && from_top) {
+                const int p = start[0] + i * step[0];
+                if (!hs && !vs)
+                    s0 = LP(lo - avail_t * ls + p);
+                else {
+                    const int xx = p << hs;
+                    const int has_left = xx || avail_l;
+                    if (vs && !j.ctu_boundary) {
+                        const int o = lo - 2 * ls + xx;
+                        const int l = has_left ? LP(o - 1) : LP(o);
+                        if (j.collocated)
+                            s0 = (LP(o - ls) + l + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+                        else {
+                            const int l1 = has_left ? LP(o - 1 + ls) : LP(o + ls);
+                            s0 = (l + l1 + 2 * (LP(o) + LP(o + ls)) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+                        }
+                    } else {
+                        const int o = lo - ls + xx;
+                        if (sl.on) {            // the row above is the CTU above: it lives in the strip
+                            const int xa = j.x0 + xx;
+                            const int l = has_left ? sl.at(xa - 1, -1) : sl.at(xa, -1);
+                            s0 = (l + 2 * sl.at(xa, -1) + sl.at(xa + 1, -1) + 2) >> 2;
+                        } else {
+                            const int l = has_left ? LP(o - 1) : LP(o);
+                            s0 = (l + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+                        }
                     }
-                } else {
-                    const int o = lo - ls + xx;
-                    const int l = has_left ? LP(o - 1) : LP(o);
-                    sel[0][i] = (l + 2 * LP(o) + LP(o + 1) + 2) >> 2;
                 }
-            }
-            for (int i = 0; i < cnt[1]; i++) {
-                if (!hs && !vs) { sel[0][cnt[0] + i] = LP(lo - avail_l + pos[1][i] * ls); continue; }
-                const int yy = pos[1][i] << vs;
-                const int o = lo - (1 + hs) * avail_l + yy * ls, l = o - avail_l;
-                int p;
-                if (!vs)
-                    p = (LP(l) + 2 * LP(o) + LP(o + 1) + 2) >> 2;
-                else if (j.collocated) {
-                    const int t = (yy || avail_t) ? LP(o - ls) : LP(o);
-                    p = (LP(l) + t + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
-                } else
-                    p = (LP(l) + LP(l + ls) + 2 * LP(o) + 2 * LP(o + ls) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
-                sel[0][cnt[0] + i] = p;
+                s1 = sb.on ? sb.at(x + p, -1) : cpl[0].ld((y - 1) * cs[0] + x + p);
+                s2 = sb.on ? sr.at(x + p, -1) : cpl[1].ld((y - 1) * cs[1] + x + p);
+            } else if (si < total) {
+                const int p = start[1] + i * step[1];
+                if (!hs && !vs)
+                    s0 = LP(lo - avail_l + p * ls);
+                else {
+                    const int yy = p << vs;
+                    const int o = lo - (1 + hs) * avail_l + yy * ls, l = o - avail_l;
+                    if (!vs)
+                        s0 = (LP(l) + 2 * LP(o) + LP(o + 1) + 2) >> 2;
+                    else if (j.collocated) {
+                        const int t = (yy || avail_t) ? ((sl.on && !yy) ? sl.at(j.x0 - (1 + hs) * avail_l, -1) : LP(o - ls)) : LP(o);
+                        s0 = (LP(l) + t + 4 * LP(o) + LP(o + 1) + LP(o + ls) + 4) >> 3;
+                    } else
+                        s0 = (LP(l) + LP(l + ls) + 2 * LP(o) + 2 * LP(o + ls) + LP(o + 1) + LP(o + 1 + ls) + 4) >> 3;
+                }
+                s1 = cpl[0].ld((y + p) * cs[0] + x - 1);
+                s2 = cpl[1].ld((y + p) * cs[1] + x - 1);
             }
 #undef LP
-            for (int c = 0; c < 2; c++) {
-                for (int i = 0; i < cnt[0]; i++)
-                    sel[c + 1][i] = cpl[c].ld((y - 1) * cs[c] + x + pos[0][i]);
-                for (int i = 0; i < cnt[1]; i++)
-                    sel[c + 1][cnt[0] + i] = cpl[c].ld((y + pos[1][i]) * cs[c] + x - 1);
-            }
-            if (cnt[0] + cnt[1] == 2)
-                for (int c = 0; c < 3; c++) {
-                    sel[c][3] = sel[c][0]; sel[c][2] = sel[c][1]; sel[c][0] = sel[c][1]; sel[c][1] = sel[c][3];
-                }
+            const int l0 = __builtin_amdgcn_readlane(s0, 0), l1 = __builtin_amdgcn_readlane(s0, 1);
+            const int l2 = __builtin_amdgcn_readlane(s0, 2), l3 = __builtin_amdgcn_readlane(s0, 3);
+            const int lv[4] = { l0, l1, l2, l3 };
             int mn0 = 0, mn1 = 2, mx0 = 1, mx1 = 3, t;
 #define SWAP(p, q) do { t = p; p = q; q = t; } while (0)
-            if (sel[0][mn0] > sel[0][mn1]) SWAP(mn0, mn1);
-            if (sel[0][mx0] > sel[0][mx1]) SWAP(mx0, mx1);
-            if (sel[0][mn0] > sel[0][mx1]) { SWAP(mn0, mx0); SWAP(mn1, mx1); }
-            if (sel[0][mn1] > sel[0][mx0]) SWAP(mn1, mx0);
+#define LV(i) ((i) == 0 ? lv[0] : (i) == 1 ? lv[1] : (i) == 2 ? lv[2] : lv[3])
+            if (LV(mn0) > LV(mn1)) SWAP(mn0, mn1);
+            if (LV(mx0) > LV(mx1)) SWAP(mx0, mx1);
+            if (LV(mn0) > LV(mx1)) { SWAP(mn0, mx0); SWAP(mn1, mx1); }
+            if (LV(mn1) > LV(mx0)) SWAP(mn1, mx0);
+#undef LV
 #undef SWAP
+            const int sv[3] = { s0, s1, s2 };
             int vmax[3], vmin[3];
+#pragma unroll
             for (int c = 0; c < 3; c++) {
-                vmax[c] = (sel[c][mx0] + sel[c][mx1] + 1) >> 1;
-                vmin[c] = (sel[c][mn0] + sel[c][mn1] + 1) >> 1;
+                vmax[c] = (__builtin_amdgcn_readlane(sv[c], mx0) + __builtin_amdgcn_readlane(sv[c], mx1) + 1) >> 1;
+                vmin[c] = (__builtin_amdgcn_readlane(sv[c], mn0) + __builtin_amdgcn_readlane(sv[c], mn1) + 1) >> 1;
             }
             const int diff = vmax[0] - vmin[0];
-            for (int i = 0; i < 2; i++) {
-                if (!diff) { a[i] = k[i] = 0; b[i] = vmin[i + 1]; continue; }
-                const int div_sig[16] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 };
-                const int diffc = vmax[i + 1] - vmin[i + 1];
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++) {
+                if (!diff) { a[i2] = k[i2] = 0; b[i2] = vmin[i2 + 1]; continue; }
+                // div_sig[] = { 0, 7, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 1, 1, 0 } as nibbles
+                const int diffc = vmax[i2 + 1] - vmin[i2 + 1];
                 int xl = ilog2(diff);
                 const int norm = ((diff << 4) >> xl) & 15;
                 xl += norm ? 1 : 0;
                 const int yl = abs(diffc) > 0 ? ilog2(abs(diffc)) + 1 : 0;
-                const int v = div_sig[norm] | 8;
-                a[i] = (diffc * v + ((1 << yl) >> 1)) >> yl;
-                k[i] = max(1, 3 + xl - yl);
+                const int v = (int)((0x0111122334455670ull >> (4 * norm)) & 15) | 8;
+                a[i2] = (diffc * v + ((1 << yl) >> 1)) >> yl;
+                k[i2] = max(1, 3 + xl - yl);
                 if (3 + xl - yl < 1)
-                    a[i] = sign_of(a[i]) * 15;
-                b[i] = vmin[i + 1] - ((a[i] * vmin[0]) >> k[i]);
+                    a[i2] = sign_of(a[i2]) * 15;
+                b[i2] = vmin[i2 + 1] - ((a[i2] * vmin[0]) >> k[i2]);
             }
         }
-        prm[0] = a[0]; prm[1] = a[1]; prm[2] = b[0]; prm[3] = b[1]; prm[4] = k[0]; prm[5] = k[1];
+        if (tid == 0) {
+            prm[0] = a[0]; prm[1] = a[1]; prm[2] = b[0]; prm[3] = b[1]; prm[4] = k[0]; prm[5] = k[1];
+        }
     }
     group_sync<NT>();
+    const int lw = ilog2(w);                    // block sides are powers of two
     for (int i = tid; i < w * h; i += NT) {
-        const int yy = i / w, xx = i - yy * w;
-        const int dsy = cclm_ds_luma<BD>(j, luma, ls, xx, yy);
+        const int yy = i >> lw, xx = i & (w - 1);
+        const int dsy = cclm_ds_luma<BD>(j, luma, ls, xx, yy, sl);
 #pragma unroll
         for (int c = 0; c < 2; c++)
             cpl[c].st((y + yy) * cs[c] + x + xx, clip_px<BD>(((dsy * prm[c]) >> prm[4 + c]) + prm[2 + c]));
@@ -840,27 +949,32 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 
 namespace vvc355 {
 
-struct ReconArea { int16_t x, y, w, h; };
+// a reconstructed area of the current CTU: x, y relative to the CTU's origin and w, h (<= 128), one byte each, in the channel type's
+// sample units (the reference restarts the list with every CTU, vvc_intra.c:508, and every area lies in that CTU)
+struct ReconArea { int x, y, w, h; };
+__device__ __forceinline__ uint32_t recon_area_pack(int x, int y, int w, int h) { return (uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24); }
+__device__ __forceinline__ ReconArea recon_area_unpack(uint32_t v, int ox, int oy) { return ReconArea{ ox + (int)(v & 255), oy + (int)((v >> 8) & 255), (int)((v >> 16) & 255), (int)(v >> 24) }; }
 struct ReconLds {
     uint16_t arr[2][4][kEdgeLen];     // edge arrays, scratch and CCLM parameters per role (luma wave, chroma wave)
     int scratch[2][16];
     int prm[2][8];
-    ReconArea ras[2][1024];           // MAX_PARTS_IN_CTU (vvc_ctu.h:38) reconstructed areas per channel type, in decoding order
-    volatile int luma_done;           // commands the luma wave has passed (the chroma wave waits on it before CCLM)
+    uint32_t ras[2][1024];            // MAX_PARTS_IN_CTU (vvc_ctu.h:38) reconstructed areas per channel type, in decoding order
+    int luma_done;                    // commands the luma wave has passed (the chroma wave waits on it before CCLM)
     int bc[8];
+    IntraTabsLds tabs;                // the predictors' constant tables (filled while the CTU waits for its neighbours)
 };
-struct ReconCtx { int ctb_up, ctb_left, ctb_up_left, end_of_tiles_x; };
+struct ReconCtx { int ctb_up, ctb_left, ctb_up_left, end_of_tiles_x, ox, oy; };       // ox, oy: the CTU's origin (luma samples)
 
 // get_reconstructed_area (vvc_intra.c:574-589) by one wave, every lane with the same (x, y): the list is scanned from its end, 64
 // areas per step; the first event in list order decides — a hit returns that area, an area wholly up-left of the point ends the
 // search ("it's too far away, no need check it") — exactly the serial walk's result
-__device__ int recon_find_area(const ReconLds &L, int ch, int n, int x, int y, int lane)
+__device__ int recon_find_area(const ReconLds &L, int ch, int n, int x, int y, int lane, int ox, int oy)
 {
     for (int base = n - 1; base >= 0; base -= 64) {
         const int i = base - lane;
         bool hit = false, stop = false;
         if (i >= 0) {
-            const ReconArea a = L.ras[ch][i];
+            const ReconArea a = recon_area_unpack(L.ras[ch][i], ox, oy);
             const int r = a.x + a.w, b = a.y + a.h;
             hit = a.x <= x && x < r && a.y <= y && y < b;
             stop = x >= r && y >= b;
@@ -890,9 +1004,11 @@ __device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &
         return target;
     }
     target = max(0, min(target, max_x - x));
+    const int ox = cx.ox >> hs, oy = cx.oy >> vs;
     int px = x, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, px, y - 1, lane)) >= 0) {
-        const int sz = min(target, L.ras[c_idx > 0][i].x + L.ras[c_idx > 0][i].w - px);
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, px, y - 1, lane, ox, oy)) >= 0) {
+        const ReconArea a = recon_area_unpack(L.ras[c_idx > 0][i], ox, oy);
+        const int sz = min(target, a.x + a.w - px);
         px += sz;
         target -= sz;
     }
@@ -910,9 +1026,11 @@ __device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx 
     target = max(0, min(target, max_y - y));
     if (!x0b)
         return target;
+    const int ox = cx.ox >> hs, oy = cx.oy >> vs;
     int py = y, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, x - 1, py, lane)) >= 0) {
-        const int sz = min(target, L.ras[c_idx > 0][i].y + L.ras[c_idx > 0][i].h - py);
+    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, x - 1, py, lane, ox, oy)) >= 0) {
+        const ReconArea a = recon_area_unpack(L.ras[c_idx > 0][i], ox, oy);
+        const int sz = min(target, a.y + a.h - py);
         py += sz;
         target -= sz;
     }
@@ -931,7 +1049,17 @@ __host__ __device__ inline int wide_angle_mode(int isp_split, int c_idx, int tb_
     return mode;
 }
 
-static constexpr int kReconFlags = 16;        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done
+
+static constexpr int kReconFlags = 16;
+#define VVC355_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ void recon_luma_done_set(ReconLds &L, int v)
+{
+    __hip_atomic_store((VVC355_LDS int *)&L.luma_done, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int recon_luma_done_get(ReconLds &L)
+{
+    return __hip_atomic_load((VVC355_LDS int *)&L.luma_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done
 
 // one wave per CTU and channel type: a CTU's blocks are a dependent chain (each reads what the previous ones wrote), so more lanes
 // per block would only add workgroup barriers to every link.  TILE (4:2:0, CTUs up to 128x128): the CTU's three component blocks live in LDS for the whole
@@ -946,49 +1074,109 @@ __device__ __forceinline__ void recon_sync_mem()
     __builtin_amdgcn_wave_barrier();
 }
 
-static constexpr int kApr = 4;                                    // apron rows above / columns to the left (ref_idx 3 reads line -4)
-static constexpr int kTileLumaP = kApr + 2 * 128 + 4, kTileLumaH = kApr + 128;          // 264 x 132
-static constexpr int kTileChromaP = kApr + 2 * 64 + 4, kTileChromaH = kApr + 64;        // 136 x 68
-static constexpr int kTileSamples = kTileLumaP * kTileLumaH + 2 * kTileChromaP * kTileChromaH;
+// CTU body tiles: rows 0 .. ctb - 1, columns -kApr .. ctb - 1 (the left apron holds the left neighbour's last columns); strips: the
+// kApr rows above, columns -kApr .. 2 ctb - 1.  Luma 128 x 136 + 4 x 264, each chroma 64 x 68 + 4 x 136: 56.5 KB with the walk's own
+// state below it — two CTUs per CU.
+static constexpr int kBodyLumaP = kApr + 128 + 4, kBodyChromaP = kApr + 64;                    // 136, 68
+static constexpr int kStripLumaP = kApr + 2 * 128 + 4, kStripChromaP = kApr + 2 * 64 + 4;      // 264, 136
+static constexpr int kBodyLuma = 128 * kBodyLumaP, kBodyChroma = 64 * kBodyChromaP;
+static constexpr int kStripLuma = kApr * kStripLumaP, kStripChroma = kApr * kStripChromaP;
+static constexpr int kTileSamples = kBodyLuma + 2 * kBodyChroma + kStripLuma + 2 * kStripChroma;
 
-// rows -kApr .. ch - 1 of one component around the CTU at (ox, oy): above the CTU 2 * ctb + kApr columns, inside it ctb + kApr;
-// coordinates clamped to the picture (samples outside it are never referenced: the availability process stops there)
+// four samples of a plane row as the tile holds them (uint16 each); x may hang over the picture's left / right edge (samples there
+// are never referenced: the availability process stops at the picture; they are clamped so that no load leaves the plane)
 template <int BD>
-__device__ void recon_tile_load(uint16_t *tile, int pitch, const uint8_t *plane, int stride, int ox, int oy, int ch, int ctb, int pic_w, int pic_h, int lane)
+__device__ __forceinline__ uint2 recon_chunk_load(const uint8_t *plane, int stride, int x, int y, int pic_w, int pic_h)
 {
     using px_t = typename Px<BD>::type;
-    const int nk_top = (kApr + 2 * ctb) / 4, nk_in = (kApr + ctb) / 4;
-    const int total = kApr * nk_top + ch * nk_in;
-    for (int i = lane; i < total; i += 64) {
-        int r, k;
-        if (i < kApr * nk_top) { r = i / nk_top; k = i - r * nk_top; r -= kApr; }
-        else { const int q = i - kApr * nk_top; r = q / nk_in; k = q - r * nk_in; }
-        const int y = clip3(oy + r, 0, pic_h - 1), x0 = ox - kApr + 4 * k;
-        uint16_t *d = tile + (r + kApr) * pitch + 4 * k;
-        if (x0 >= 0 && x0 + 3 < pic_w) {
-            const uint8_t *p = plane + row_off(y, stride) + x0 * (int)sizeof(px_t);
-            if (BD > 8) {
-                *(uint2 *)d = gld<uint2>(p);
-            } else {
-                const uint32_t q = gld<uint32_t>(p);
-                *(uint2 *)d = make_uint2(__builtin_amdgcn_perm(0, q, 0x0c010c00u), __builtin_amdgcn_perm(0, q, 0x0c030c02u));
-            }
-        } else {
+    y = clip3(y, 0, pic_h - 1);
+    if (x >= 0 && x + 3 < pic_w) {
+        const uint8_t *p = plane + row_off(y, stride) + x * (int)sizeof(px_t);
+        if (BD > 8)
+            return gld<uint2>(p);
+        const uint32_t q = gld<uint32_t>(p);
+        return make_uint2(__builtin_amdgcn_perm(0, q, 0x0c010c00u), __builtin_amdgcn_perm(0, q, 0x0c030c02u));
+    }
+    uint32_t e[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                d[e] = (uint16_t)ld_px<BD>(plane + row_off(y, stride), clip3(x0 + e, 0, pic_w - 1));
+    for (int i = 0; i < 4; i++)
+        e[i] = (uint32_t)ld_px<BD>(plane + row_off(y, stride), clip3(x + i, 0, pic_w - 1));
+    return make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+}
+// The CTU's own cw x ch samples -> the body tile (columns kApr ..).  Nothing here depends on the neighbours, so this runs BEFORE the
+// wait on their flags.  LK = log2 of the chunk slots per row (5: luma, 4: chroma): 64 >> LK rows per step, eight steps' loads in flight.
+template <int BD, int LK>
+__device__ void recon_body_load(uint16_t *tile, int pitch, const uint8_t *plane, int stride, int ox, int oy, int cw, int ch, int pic_w, int pic_h, int lane)
+{
+    constexpr int RPS = 64 >> LK;
+    const int k = lane & ((1 << LK) - 1), r0 = lane >> LK;
+    if (4 * k >= cw)
+        return;
+    uint16_t *d = tile + r0 * pitch + kApr + 4 * k;
+    for (int r = r0; r < ch; r += RPS * 8) {
+        uint2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (r + u * RPS < ch)
+                v[u] = recon_chunk_load<BD>(plane, stride, ox + 4 * k, oy + r + u * RPS, pic_w, pic_h);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (r + u * RPS < ch)
+                *(uint2 *)(d + (r - r0 + u * RPS) * pitch) = v[u];
+    }
+}
+// What the neighbours wrote: the kApr columns left of the CTU (-> the body tile's apron) and the kApr rows above it, reaching one
+// CTU to the right (-> the strip); after the wait.  All of a lane's loads are issued before its first LDS store.
+template <int BD>
+__device__ void recon_edges_load(uint16_t *tile, int pitch, uint16_t *strip, int spitch, const uint8_t *plane, int stride, int ox, int oy, int ctbc, int ch,
+                                 int pic_w, int pic_h, int lane)
+{
+    uint2 va[2], vs[5];
+    const int n4 = (kApr + 2 * ctbc) / 4;            // chunks per strip row (at most 65)
+    if (ox > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (lane + 64 * u < ch)
+                va[u] = recon_chunk_load<BD>(plane, stride, ox - kApr, oy + lane + 64 * u, pic_w, pic_h);
+    }
+    if (oy > 0) {
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = lane + 64 * u;
+            if (i < kApr * n4) {
+                const int r = (i >= n4) + (i >= 2 * n4) + (i >= 3 * n4), k = i - r * n4;
+                vs[u] = recon_chunk_load<BD>(plane, stride, ox - kApr + 4 * k, oy - kApr + r, pic_w, pic_h);
+            }
+        }
+    }
+    if (ox > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (lane + 64 * u < ch)
+                *(uint2 *)(tile + (lane + 64 * u) * pitch) = va[u];
+    }
+    if (oy > 0) {
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = lane + 64 * u;
+            if (i < kApr * n4) {
+                const int r = (i >= n4) + (i >= 2 * n4) + (i >= 3 * n4), k = i - r * n4;
+                *(uint2 *)(strip + r * spitch + 4 * k) = vs[u];
+            }
         }
     }
 }
-// the CTU's own cw x ch samples back to the plane
-template <int BD>
-__device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane, int stride, int ox, int oy, int cw, int ch, int lane)
+// rows [r_lo, r_hi) x chunks [k_lo, k_hi) of the CTU's own samples back to the plane
+template <int BD, int LK>
+__device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane, int stride, int ox, int oy, int r_lo, int r_hi, int k_lo, int k_hi, int lane)
 {
     using px_t = typename Px<BD>::type;
-    const int nk = cw / 4, total = ch * nk;
-    for (int i = lane; i < total; i += 64) {
-        const int r = i / nk, k = i - r * nk;
-        const uint2 v = *(const uint2 *)(tile + (r + kApr) * pitch + kApr + 4 * k);
+    constexpr int RPS = 64 >> LK;
+    const int k = k_lo + (lane & ((1 << LK) - 1));
+    if (k >= k_hi)
+        return;
+    for (int r = r_lo + (lane >> LK); r < r_hi; r += RPS) {
+        const uint2 v = *(const uint2 *)(tile + r * pitch + kApr + 4 * k);
         uint8_t *p = plane + row_off(oy + r, stride) + (ox + 4 * k) * (int)sizeof(px_t);
         if (BD > 8)
             gst<uint2>(p, v);
@@ -997,26 +1185,26 @@ __device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane
     }
 }
 
+// one CTU: takes the next ticket, returns false when none is left
 template <int BD, bool TILE>
-__global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon_frame *__restrict__ fp)
+__device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, ReconLds &L, uint16_t *tiles, const int role, const int tid)
 {
-    __shared__ ReconLds L;
-    __shared__ __attribute__((aligned(16))) uint16_t tiles[TILE ? kTileSamples : 8];
     using px_t = typename Px<BD>::type;
     using PX = typename std::conditional<TILE, LPix, GPix<BD>>::type;
-    const vvc355_recon_frame f = load_uniform(fp);
-    int *state = (int *)f.state;
-    // two waves per CTU: wave 0 walks the luma commands, wave 1 the chroma commands.  The two chains only meet at CCLM (chroma
-    // predicted from the coding unit's reconstructed luma): the chroma wave waits there until the luma wave has passed that command.
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
-    if (threadIdx.x == 0) {
-        L.bc[0] = atomicAdd(&state[0], 1);
-        L.luma_done = 0;
+    VVC355_GLOBAL int *state = (VVC355_GLOBAL int *)f.state;
+    // Every branch around a workgroup barrier in this loop is wave-uniform (whole waves take it, lanes write identical values where
+    // one lane would do): a lane-0-only block next to the loop's back edge lets the compiler's control-flow structurizer move that
+    // lane's code across the barrier of the next iteration.
+    if (role == 0) {
+        // lane 0 adds 1, the other lanes 0: lane 0's return value is the ticket
+        const int t = __hip_atomic_fetch_add(&state[0], tid == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.bc[0] = __builtin_amdgcn_readfirstlane(t);
+        recon_luma_done_set(L, 0);
     }
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(L.bc[0]);
     if (ticket >= f.n_work)
-        return;
+        return false;
     const int rs = __builtin_amdgcn_readfirstlane(gld<int>((const int *)f.order + ticket));
     const vvc355_recon_ctu *ctus = (const vvc355_recon_ctu *)f.ctus;
     const vvc355_recon_ctu ctu = load_uniform(ctus + rs);
@@ -1035,78 +1223,114 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
         cx.ctb_left = rx > 0 && !left_tile;
         cx.ctb_up = ry > 0 && !upper_tile && !upper_slice;
         cx.ctb_up_left = cx.ctb_left && cx.ctb_up;
+        cx.ox = rx * ctb; cx.oy = ry * ctb;
+    }
+    // the three planes as the walk sees them: accessor of sample (0, 0) + stride in pixels
+    PX pl0, pl1, pl2;
+    int ps0, ps1;                       // strides in pixels: luma, chroma
+    constexpr int kTileOff[3] = { 0, kBodyLuma, kBodyLuma + kBodyChroma };
+    constexpr int kStripOff[3] = { kBodyLuma + 2 * kBodyChroma, kBodyLuma + 2 * kBodyChroma + kStripLuma, kBodyLuma + 2 * kBodyChroma + kStripLuma + kStripChroma };
+    StripRef st0 = kNoStrip, st1 = kNoStrip, st2 = kNoStrip;
+    const int cw0 = min(ctb, f.width - rx * ctb), ch0 = min(ctb, f.height - ry * ctb);
+    // (TILE) this CTU's own samples -> LDS: they do not depend on the neighbours, so the loads overlap the wait
+    if constexpr (TILE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sh = c ? 1 : 0, pitch = c ? kBodyChromaP : kBodyLumaP, spitch = c ? kStripChromaP : kStripLumaP;
+            const int ox = (rx * ctb) >> sh, oy = (ry * ctb) >> sh;
+            if ((c == 0) == (role == 0)) {     // the luma wave brings in the luma tile, the chroma wave both chroma tiles
+                if (c == 0)
+                    recon_body_load<BD, 5>(tiles + kTileOff[c], pitch, (const uint8_t *)f.plane[c], f.stride[c], ox, oy, cw0, ch0, f.width, f.height, tid);
+                else
+                    recon_body_load<BD, 4>(tiles + kTileOff[c], pitch, (const uint8_t *)f.plane[c], f.stride[c], ox, oy, cw0 >> 1, ch0 >> 1, f.width >> 1, f.height >> 1, tid);
+            }
+            const LPix px{ tiles, kTileOff[c] - oy * pitch + (kApr - ox) };
+            const StripRef sx{ tiles + kStripOff[c], spitch, ox - kApr, false };
+            if (c == 0) { pl0 = px; st0 = sx; } else if (c == 1) { pl1 = px; st1 = sx; } else { pl2 = px; st2 = sx; }
+        }
+        ps0 = kBodyLumaP; ps1 = kBodyChromaP;
     }
     // wait for the neighbours this CTU reads: left, upper-left, upper, upper-right (those that have commands)
-    if (threadIdx.x == 0) {
+    const unsigned long long t_wait = RPROF_NOW();
+    if (role == 0) {
         const int dep[4] = { rx > 0 ? rs - 1 : -1, (rx > 0 && ry > 0) ? rs - ncx - 1 : -1, ry > 0 ? rs - ncx : -1, (ry > 0 && rx + 1 < ncx) ? rs - ncx + 1 : -1 };
+#pragma unroll
         for (int d = 0; d < 4; d++) {
-            if (dep[d] < 0 || gld<uint32_t>(&ctus[dep[d]].n_cmd) == 0)
+            if (dep[d] < 0 || __builtin_amdgcn_readfirstlane(gld<uint32_t>(&ctus[dep[d]].n_cmd)) == 0)
                 continue;
-            while (__hip_atomic_load(&state[kReconFlags + dep[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&state[kReconFlags + dep[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
                 __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-
-    // the three planes as the walk sees them: accessor of sample (0, 0) + stride in pixels
-    PX pl[3];
-    int ps[3];
-    uint16_t *tile_c[3] = { tiles, tiles + kTileLumaP * kTileLumaH, tiles + kTileLumaP * kTileLumaH + kTileChromaP * kTileChromaH };
-    const int cw0 = min(ctb, f.width - rx * ctb), ch0 = min(ctb, f.height - ry * ctb);
+    RPROF_ADD(1 + 32 * role, t_wait);
+    RPROF_INC(0 + 32 * role);
+    const unsigned long long t_load = RPROF_NOW();
     if constexpr (TILE) {
+        // what the neighbours wrote: left apron and the rows above
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int sh = c ? 1 : 0, pitch = c ? kTileChromaP : kTileLumaP;
-            const int ox = (rx * ctb) >> sh, oy = (ry * ctb) >> sh;
-            if ((c == 0) == (role == 0))       // the luma wave brings in the luma tile, the chroma wave both chroma tiles
-                recon_tile_load<BD>(tile_c[c], pitch, (const uint8_t *)f.plane[c], f.stride[c], ox, oy, ch0 >> sh, ctb >> sh, f.width >> sh, f.height >> sh, tid);
-            pl[c] = LPix{ tile_c[c], (kApr - oy) * pitch + (kApr - ox) };
-            ps[c] = pitch;
+            const int sh = c ? 1 : 0;
+            if ((c == 0) == (role == 0))
+                recon_edges_load<BD>(tiles + kTileOff[c], c ? kBodyChromaP : kBodyLumaP, tiles + kStripOff[c], c ? kStripChromaP : kStripLumaP, (const uint8_t *)f.plane[c], f.stride[c],
+                                     (rx * ctb) >> sh, (ry * ctb) >> sh, ctb >> sh, ch0 >> sh, f.width >> sh, f.height >> sh, tid);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            pl[c] = GPix<BD>{ (uint8_t *)f.plane[c] };
-            ps[c] = f.stride[c] / (int)sizeof(px_t);
-        }
+        pl0 = GPix<BD>{ (uint8_t *)f.plane[0] }; pl1 = GPix<BD>{ (uint8_t *)f.plane[1] }; pl2 = GPix<BD>{ (uint8_t *)f.plane[2] };
+        ps0 = f.stride[0] / (int)sizeof(px_t); ps1 = f.stride[1] / (int)sizeof(px_t);
     }
 
+    RPROF_ADD(2 + 32 * role, t_load);
+    const unsigned long long t_loop = RPROF_NOW();
+#ifdef VVC355_RECON_PROF
+    const long long c_loop = clock64();
+#endif
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
     const int ctb_mask = ctb - 1;
     constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
-    // commands are fetched one ahead through the vector-memory path (its counter is not shared with LDS traffic, so the fetch
-    // really overlaps the previous block): lane i holds dword i of the command
-    uint32_t cmd_dw = gld<uint32_t>((const uint32_t *)cmds + min(tid, CMD_DW - 1));
+    // commands come in chunks of six (60 dwords, lane i holds dword i of the chunk) through the vector-memory path, the next chunk
+    // fetched while this one is walked (its counter is not shared with LDS traffic, so the fetch really overlaps the blocks)
+    constexpr int CHUNK = 6;
+    const uint32_t n_dw = ctu.n_cmd * CMD_DW;
+    uint32_t next_dw = gld<uint32_t>((const uint32_t *)cmds + min((uint32_t)tid, n_dw - 1)), cur_dw = 0;
     int n_own = 0, n_luma_seen = 0;      // areas this wave has recorded in its channel type's list; luma areas recorded before the current command
     uint16_t (*arr)[kEdgeLen] = L.arr[role];
+    const LTabs tabs{ &L.tabs };
+    int slot = CHUNK;
     for (uint32_t k = 0; k < ctu.n_cmd; k++) {
+        if (slot == CHUNK) {
+            slot = 0;
+            cur_dw = next_dw;
+            next_dw = gld<uint32_t>((const uint32_t *)cmds + min((k + CHUNK) * CMD_DW + (uint32_t)tid, n_dw - 1));
+        }
+        const int lane0 = slot * CMD_DW;
+        slot++;
         vvc355_recon_cmd c;
         {
+            // dword 6 = mode, kind, c_idx, ref_idx: enough to pass over the other wave's commands
+            const uint32_t w6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + 6);
+            if ((((w6 >> 16) & 0xff) > 0) != (role == 1)) {
+                if (((w6 >> 8) & 0xff) == VVC355_RECON_MARK)
+                    n_luma_seen++;              // the chroma wave keeps count of the luma areas recorded so far (CCLM's availability reads that list)
+                if (role == 0)
+                    recon_luma_done_set(L, (int)k + 1);
+                continue;
+            }
             uint32_t w[CMD_DW];
 #pragma unroll
-            for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)cmd_dw, i);
+            for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + i);
             __builtin_memcpy(&c, w, sizeof(c));
-            cmd_dw = gld<uint32_t>((const uint32_t *)(cmds + min(k + 1, ctu.n_cmd - 1)) + min(tid, CMD_DW - 1));
         }
-        const bool mine = (c.c_idx > 0) == (role == 1);
-        if (!mine) {
-            // the other wave's command; the chroma wave keeps count of the luma areas recorded so far (CCLM's availability reads that list)
-            if (c.kind == VVC355_RECON_MARK)
-                n_luma_seen++;
-            if (role == 0 && tid == 0)
-                L.luma_done = (int)k + 1;
-            continue;
-        }
+        const unsigned long long t_cmd = RPROF_NOW();
         if (c.kind == VVC355_RECON_MARK) {
             // add_reconstructed_area (vvc_intra.c:188-206)
             const int ch = c.c_idx > 0, hs = ch ? f.hs : 0, vs = ch ? f.vs : 0;
             if (n_own < 1024) {
-                if (tid == 0)
-                    L.ras[ch][n_own] = ReconArea{ (int16_t)(c.x0 >> hs), (int16_t)(c.y0 >> vs), (int16_t)(c.w >> hs), (int16_t)(c.h >> vs) };
+                L.ras[ch][n_own] = recon_area_pack((c.x0 - cx.ox) >> hs, (c.y0 - cx.oy) >> vs, c.w >> hs, c.h >> vs);
                 n_own++;
             }
             group_sync<64>();
@@ -1127,12 +1351,15 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
                 const bool cand_up = cx.ctb_up || y0b, cand_left = cx.ctb_left || x0b;
                 j.cand_up_left = (x0b || y0b) ? (cand_left && cand_up) : cx.ctb_up_left;
             }
-            const PX plane = c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2];
-            intra_pred_body<BD, 64>(j, plane, c_idx ? ps[1] : ps[0], arr, L.scratch[role], tid);
+            const PX plane = pick3(c_idx, pl0, pl1, pl2);
+            StripRef sr = pick3(c_idx, st0, st1, st2);
+            sr.on = TILE && (y & ((ctb >> vs) - 1)) == 0;          // the block sits on the CTU's top edge: the rows above it are the strip
+            RPROF_ADD(6 + 32 * role, t_cmd);
+            intra_pred_body<BD, 64>(j, plane, c_idx ? ps1 : ps0, arr, L.scratch[role], tid, sr, tabs);
             if (TILE) group_sync<64>(); else recon_sync_mem();
         } else if (c.kind == VVC355_RECON_CCLM) {
             // the coding unit's luma (every luma command before this one) must be reconstructed
-            while (L.luma_done < (int)k)
+            while (recon_luma_done_get(L) < (int)k)
                 __builtin_amdgcn_s_sleep(1);
             group_sync<64>();
             vvc355_cclm_job j = {};
@@ -1144,15 +1371,17 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
             j.avail_l = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_luma_seen, c.cu_y0, c.x0, c.y0, 1, 0, tid)) != 0);
             j.collocated = f.collocated;
             j.ctu_boundary = (c.y0 & ctb_mask) == 0;
-            cclm_body<BD, 64>(j, pl[0], ps[0], pl[1], pl[2], ps[1], ps[2], L.prm[1], tid);
+            StripRef s0 = st0, s1 = st1, s2 = st2;
+            s0.on = s1.on = s2.on = TILE && j.ctu_boundary;
+            cclm_body<BD, 64>(j, pl0, ps0, pl1, pl2, ps1, ps1, L.prm[1], tid, s0, s1, s2);
             if (TILE) group_sync<64>(); else recon_sync_mem();
         } else if (c.kind == VVC355_RECON_CIIP) {
             // inter.put_ciip (vvc_inter_template.c:60) of a combined inter / intra block (pred_regular_luma / _chroma, vvc_inter.c:570-575,
             // :632-638): the intra prediction the previous command left in the picture, weighted against the inter prediction of the
             // batched stage (c.resid: w x h pixels, packed rows); c.joint = ciip_derive_intra_weight (:530-548)
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w >> hs, n = w * (c.h >> vs);
-            const int stride = c_idx ? ps[1] : ps[0], iw = c.joint;
-            const PX dst = (c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2]).at((c.y0 >> vs) * stride + (c.x0 >> hs));
+            const int stride = c_idx ? ps1 : ps0, iw = c.joint;
+            const PX dst = pick3(c_idx, pl0, pl1, pl2).at((c.y0 >> vs) * stride + (c.x0 >> hs));
             const uint8_t *inter = (const uint8_t *)c.resid;
             const int lw = ilog2i(w);
             for (int i = tid; i < n; i += 64) {
@@ -1163,8 +1392,8 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
         } else {
             // RESID: itx.add_residual / add_residual_joint (vvcdsp_template.c:32,48) of the block the transform stage left in c.resid
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0, w = c.w, n = w * c.h;
-            const PX dst = (c_idx == 0 ? pl[0] : c_idx == 1 ? pl[1] : pl[2]).at((c.y0 >> vs) * (c_idx ? ps[1] : ps[0]) + (c.x0 >> hs));
-            const int stride = c_idx ? ps[1] : ps[0];
+            const int stride = c_idx ? ps1 : ps0;
+            const PX dst = pick3(c_idx, pl0, pl1, pl2).at((c.y0 >> vs) * stride + (c.x0 >> hs));
             const int *res = (const int *)c.resid;
             const int lw = ilog2i(w);
             for (int i = tid * 4; i < n; i += 256) {          // w >= 4: four samples of one row per lane and step
@@ -1180,32 +1409,109 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
             }
             if (TILE) group_sync<64>(); else recon_sync_mem();
         }
-        if (role == 0 && tid == 0)
-            L.luma_done = (int)k + 1;          // issued after the command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
+        if (role == 0)
+            recon_luma_done_set(L, (int)k + 1);          // issued after the command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
+        RPROF_ADD(9 + (int)c.kind + 32 * role, t_cmd);
+        RPROF_INC(17 + (int)c.kind + 32 * role);
     }
+    RPROF_ADD(3 + 32 * role, t_loop);
+#ifdef VVC355_RECON_PROF
+    atomicAdd(&vvc355_recon_prof[7 + 32 * role], tid == 0 ? (unsigned long long)(clock64() - c_loop) : 0ull);
+#endif
+    const unsigned long long t_join = RPROF_NOW();
     __syncthreads();
+    RPROF_ADD(4 + 32 * role, t_join);
+    const unsigned long long t_store = RPROF_NOW();
+    // publish: first what the neighbours read (the CTU's last kApr rows and columns), both waves' stores out of the CU, then one lane
+    // releases and raises the flag; the rest of the tile goes out behind the flag (no other CTU reads it in this pass)
     if constexpr (TILE) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int sh = c ? 1 : 0;
-            if ((c == 0) == (role == 0))
-                recon_tile_store<BD>(tile_c[c], c ? kTileChromaP : kTileLumaP, (uint8_t *)f.plane[c], f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh,
-                                     cw0 >> sh, ch0 >> sh, tid);
+            const int sh = c ? 1 : 0, pitch = c ? kBodyChromaP : kBodyLumaP, nk = cw0 >> (2 + sh), nr = ch0 >> sh;
+            if ((c == 0) != (role == 0))
+                continue;
+            uint8_t *plane = (uint8_t *)f.plane[c];
+            if (c == 0) {
+                recon_tile_store<BD, 5>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, max(nr - kApr, 0), nr, 0, nk, tid);
+                recon_tile_store<BD, 0>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), nk - 1, nk, tid);
+            } else {
+                recon_tile_store<BD, 4>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, max(nr - kApr, 0), nr, 0, nk, tid);
+                recon_tile_store<BD, 0>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), nk - 1, nk, tid);
+            }
         }
     }
-    // publish: both waves' stores have left the CU, then one lane releases and raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (role == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (TILE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sh = c ? 1 : 0, pitch = c ? kBodyChromaP : kBodyLumaP, nk = cw0 >> (2 + sh), nr = ch0 >> sh;
+            if ((c == 0) != (role == 0))
+                continue;
+            if (c == 0)
+                recon_tile_store<BD, 5>(tiles + kTileOff[c], pitch, (uint8_t *)f.plane[c], f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), 0, nk - 1, tid);
+            else
+                recon_tile_store<BD, 4>(tiles + kTileOff[c], pitch, (uint8_t *)f.plane[c], f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), 0, nk - 1, tid);
+        }
+    }
+    RPROF_ADD(5 + 32 * role, t_store);
+    return true;
+}
+
+// A persistent grid: each workgroup (two waves) takes CTU tickets until none is left, so only as many CTUs as can run at once hold
+// LDS and wave slots — the rest of the device stays free for the other frames' kernels.  Any grid size is deadlock-free (tickets
+// follow the order in which CTUs become ready: every CTU a workgroup waits for has a smaller ticket, held by a running workgroup).
+template <int BD, bool TILE>
+__global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon_frame *__restrict__ fp)
+{
+    __shared__ ReconLds L;
+    __shared__ __attribute__((aligned(16))) uint16_t tiles[TILE ? kTileSamples : 8];
+    const vvc355_recon_frame f = load_uniform(fp);
+    // two waves per CTU: wave 0 walks the luma commands, wave 1 the chroma commands.  The two chains only meet at CCLM (chroma
+    // predicted from the coding unit's reconstructed luma): the chroma wave waits there until the luma wave has passed that command.
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
+    // the predictors' tables -> LDS (visible after the first CTU's barriers)
+    {
+        uint32_t *t32 = (uint32_t *)&L.tabs;
+        constexpr int N0 = 64, N1 = N0 + 256, N2 = N1 + 256, N3 = N2 + 672;
+        static_assert(sizeof(IntraTabsLds) == N3 * 4, "table copy covers the whole struct");
+        for (int i = threadIdx.x; i < N3; i += 128) {
+            const uint8_t *g = i < N0 ? (const uint8_t *)i_tab_intra_luma_filter + 4 * i
+                             : i < N1 ? i_tab_mip_matrix_4x4 + 4 * (i - N0)
+                             : i < N2 ? i_tab_mip_matrix_8x8 + 4 * (i - N1) : i_tab_mip_matrix_16x16 + 4 * (i - N2);
+            t32[i] = gld<uint32_t>(g);
+        }
+    }
+    while (recon_one_ctu<BD, TILE>(f, L, tiles, role, tid)) {
     }
 }
 
 } // namespace vvc355
 
 extern "C" {
+
+#ifdef VVC355_RECON_PROF
+void vvc355_recon_prof_read(unsigned long long *out, int reset)
+{
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vvc355::vvc355_recon_prof), sizeof(unsigned long long) * 64));
+    int dev = 0, khz = 0, ckhz = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    HIP_CHECK(hipDeviceGetAttribute(&ckhz, hipDeviceAttributeClockRate, dev));
+    out[63] = (unsigned long long)khz;
+    out[62] = (unsigned long long)ckhz;
+    if (reset) {
+        unsigned long long z[64] = {};
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vvc355::vvc355_recon_prof), z, sizeof(z)));
+    }
+}
+#endif
 
 size_t vvc355_recon_state_bytes(int n_ctus) { return sizeof(int) * (size_t)(vvc355::kReconFlags + (n_ctus > 0 ? n_ctus : 0)); }
 
@@ -1216,10 +1522,14 @@ void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *fra
     HIP_CHECK(hipMemsetAsync((void *)frame_host->state, 0, vvc355_recon_state_bytes(frame_host->ctb_width * frame_host->ctb_height), (hipStream_t)stream));
     // 4:2:0 with CTUs up to 128x128 walks on LDS tiles (picture widths are multiples of 8: whole 4-sample chunks); other formats on the planes
     const bool tile = frame_host->hs == 1 && frame_host->vs == 1 && frame_host->ctb_log2 <= 7 && frame_host->width % 8 == 0 && frame_host->height % 2 == 0;
+    // enough workgroups for the CTUs that can run at once (independent intra clusters of an inter picture; half a CTU row of an intra
+    // picture), few enough that their LDS leaves room for the other frames' kernels.  VVC355_RECON_GRID overrides (tuning aid).
+    static const int grid_env = [] { const char *e = getenv("VVC355_RECON_GRID"); return e ? atoi(e) : 0; }();
+    const int grid = std::min(frame_host->n_work, grid_env > 0 ? grid_env : 256);
     if (tile)
-        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, true>), dim3(frame_host->n_work), dim3(128), 0, (hipStream_t)stream, frame_dev));
+        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, true>), dim3(grid), dim3(128), 0, (hipStream_t)stream, frame_dev));
     else
-        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, false>), dim3(frame_host->n_work), dim3(128), 0, (hipStream_t)stream, frame_dev));
+        VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, false>), dim3(grid), dim3(128), 0, (hipStream_t)stream, frame_dev));
     HIP_CHECK(hipGetLastError());
 }
 
