@@ -19,11 +19,13 @@ namespace vvc355 {
 #undef VVC355_TABLE
 
 #ifdef VVC355_RECON_PROF
-// profiling build only (tools/dbg): 100 MHz wall-clock ticks per phase, summed over all CTUs by lane 0 of each wave
+// profiling build only (tools/dbg): 100 MHz wall-clock ticks per phase, accumulated per workgroup in LDS (every lane adds the same
+// wave-uniform value, so no branch and no atomic sits inside the walk) and flushed to the device array when the workgroup ends
 __device__ unsigned long long vvc355_recon_prof[64];
+__device__ __forceinline__ unsigned long long *rprof_lds() { __shared__ unsigned long long p[64]; return p; }
 #define RPROF_NOW() wall_clock64()
-#define RPROF_ADD(slot, t0) do { atomicAdd(&vvc355_recon_prof[slot], tid == 0 ? (unsigned long long)(wall_clock64() - (t0)) : 0ull); } while (0)
-#define RPROF_INC(slot) do { atomicAdd(&vvc355_recon_prof[slot], tid == 0 ? 1ull : 0ull); } while (0)
+#define RPROF_ADD(slot, t0) do { unsigned long long *p_ = rprof_lds(); p_[slot] = p_[slot] + (unsigned long long)(wall_clock64() - (t0)); } while (0)
+#define RPROF_INC(slot) do { unsigned long long *p_ = rprof_lds(); p_[slot] = p_[slot] + 1ull; } while (0)
 #else
 #define RPROF_NOW() 0ull
 #define RPROF_ADD(slot, t0) do { (void)(t0); } while (0)
@@ -949,47 +951,32 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 
 namespace vvc355 {
 
-// a reconstructed area of the current CTU: x, y relative to the CTU's origin and w, h (<= 128), one byte each, in the channel type's
-// sample units (the reference restarts the list with every CTU, vvc_intra.c:508, and every area lies in that CTU)
-struct ReconArea { int x, y, w, h; };
-__device__ __forceinline__ uint32_t recon_area_pack(int x, int y, int w, int h) { return (uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)w << 16) | ((uint32_t)h << 24); }
-__device__ __forceinline__ ReconArea recon_area_unpack(uint32_t v, int ox, int oy) { return ReconArea{ ox + (int)(v & 255), oy + (int)((v >> 8) & 255), (int)((v >> 16) & 255), (int)(v >> 24) }; }
 struct ReconLds {
     uint16_t arr[2][4][kEdgeLen];     // edge arrays, scratch and CCLM parameters per role (luma wave, chroma wave)
     int scratch[2][16];
     int prm[2][8];
-    uint32_t ras[2][1024];            // MAX_PARTS_IN_CTU (vvc_ctu.h:38) reconstructed areas per channel type, in decoding order
+    uint32_t rmap[2][2][32];          // reconstructed areas of this CTU per channel type as bitmaps of 4x4-luma-sample units: [0] bit b of
+                                      // word u = unit (b, u), [1] its transpose (see recon_top_available)
     int luma_done;                    // commands the luma wave has passed (the chroma wave waits on it before CCLM)
     int bc[8];
     IntraTabsLds tabs;                // the predictors' constant tables (filled while the CTU waits for its neighbours)
 };
 struct ReconCtx { int ctb_up, ctb_left, ctb_up_left, end_of_tiles_x, ox, oy; };       // ox, oy: the CTU's origin (luma samples)
 
-// get_reconstructed_area (vvc_intra.c:574-589) by one wave, every lane with the same (x, y): the list is scanned from its end, 64
-// areas per step; the first event in list order decides — a hit returns that area, an area wholly up-left of the point ends the
-// search ("it's too far away, no need check it") — exactly the serial walk's result
-__device__ int recon_find_area(const ReconLds &L, int ch, int n, int x, int y, int lane, int ox, int oy)
+// The reference keeps the CTU's reconstructed areas as a list (add_reconstructed_area, vvc_intra.c:188-206, restarted per CTU :508)
+// and answers "how many samples above / left of this block are reconstructed" by walking it (get_reconstructed_area :574-589:
+// newest area first, stop at an area wholly up-left of the point).  For the areas a decoder produces — disjoint blocks of one
+// partitioning, in coding order, positions and sizes multiples of four luma samples except the 1- and 2-row intra sub-partitions,
+// which only ever ask about their own earlier rows or about finished coding units — the walk's answer is the length of the run of
+// covered 4x4 units starting at the block: here one LDS word and a count of trailing ones.  (An area up-left of a point is never
+// coded after an area containing it, so the walk's early stop never hides a hit.)  The oracle keeps the literal list walk.
+__device__ __forceinline__ int recon_run(uint32_t line, int from)
 {
-    for (int base = n - 1; base >= 0; base -= 64) {
-        const int i = base - lane;
-        bool hit = false, stop = false;
-        if (i >= 0) {
-            const ReconArea a = recon_area_unpack(L.ras[ch][i], ox, oy);
-            const int r = a.x + a.w, b = a.y + a.h;
-            hit = a.x <= x && x < r && a.y <= y && y < b;
-            stop = x >= r && y >= b;
-        }
-        const unsigned long long hm = __ballot(hit), sm = __ballot(stop);
-        const int fh = hm ? __builtin_ctzll(hm) : 64, fs = sm ? __builtin_ctzll(sm) : 64;
-        if (fh < fs)
-            return base - fh;
-        if (fs < 64)
-            return -1;
-    }
-    return -1;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)line) >> from;
+    return m == ~0u ? 32 : __builtin_ctz(~m);
 }
 // ff_vvc_get_top_available (vvc_intra.c:591-620), one wave (uniform arguments, uniform result)
-__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int n_ras, int cu_x0, int x, int y, int target, int c_idx, int lane)
+__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_x0, int x, int y, int target, int c_idx)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int end_of_ctb_x = ((cu_x0 >> f.ctb_log2) + 1) << f.ctb_log2;
@@ -1004,18 +991,12 @@ __device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &
         return target;
     }
     target = max(0, min(target, max_x - x));
-    const int ox = cx.ox >> hs, oy = cx.oy >> vs;
-    int px = x, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, px, y - 1, lane, ox, oy)) >= 0) {
-        const ReconArea a = recon_area_unpack(L.ras[c_idx > 0][i], ox, oy);
-        const int sz = min(target, a.x + a.w - px);
-        px += sz;
-        target -= sz;
-    }
-    return px - x;
+    const int ux = ((x << hs) - cx.ox) >> 2, uy = (((y - 1) << vs) - cx.oy) >> 2;
+    const int end = (cx.ox + ((ux + recon_run(L.rmap[c_idx > 0][0][uy], ux)) << 2)) >> hs;
+    return max(0, min(target, end - x));
 }
 // ff_vvc_get_left_available (vvc_intra.c:622-648), one wave
-__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int n_ras, int cu_y0, int x, int y, int target, int c_idx, int lane)
+__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_y0, int x, int y, int target, int c_idx)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int x0b = x & ((1 << (f.ctb_log2 - hs)) - 1);
@@ -1026,15 +1007,9 @@ __device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx 
     target = max(0, min(target, max_y - y));
     if (!x0b)
         return target;
-    const int ox = cx.ox >> hs, oy = cx.oy >> vs;
-    int py = y, i;
-    while (target > 0 && (i = recon_find_area(L, c_idx > 0, n_ras, x - 1, py, lane, ox, oy)) >= 0) {
-        const ReconArea a = recon_area_unpack(L.ras[c_idx > 0][i], ox, oy);
-        const int sz = min(target, a.y + a.h - py);
-        py += sz;
-        target -= sz;
-    }
-    return py - y;
+    const int ux = (((x - 1) << hs) - cx.ox) >> 2, uy = ((y << vs) - cx.oy) >> 2;
+    const int end = (cx.oy + ((uy + recon_run(L.rmap[c_idx > 0][1][ux], uy)) << 2)) >> vs;
+    return max(0, min(target, end - y));
 }
 // ff_vvc_wide_angle_mode_mapping (vvc_intra.c:693-714)
 __host__ __device__ inline int wide_angle_mode(int isp_split, int c_idx, int tb_w, int tb_h, int cb_w, int cb_h, int mode)
@@ -1205,6 +1180,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     const int ticket = __builtin_amdgcn_readfirstlane(L.bc[0]);
     if (ticket >= f.n_work)
         return false;
+    ((uint32_t *)L.rmap[role])[tid] = 0;             // this wave's channel type starts with nothing reconstructed (seen by both waves after the next barrier)
     const int rs = __builtin_amdgcn_readfirstlane(gld<int>((const int *)f.order + ticket));
     const vvc355_recon_ctu *ctus = (const vvc355_recon_ctu *)f.ctus;
     const vvc355_recon_ctu ctu = load_uniform(ctus + rs);
@@ -1297,7 +1273,6 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     constexpr int CHUNK = 6;
     const uint32_t n_dw = ctu.n_cmd * CMD_DW;
     uint32_t next_dw = gld<uint32_t>((const uint32_t *)cmds + min((uint32_t)tid, n_dw - 1)), cur_dw = 0;
-    int n_own = 0, n_luma_seen = 0;      // areas this wave has recorded in its channel type's list; luma areas recorded before the current command
     uint16_t (*arr)[kEdgeLen] = L.arr[role];
     const LTabs tabs{ &L.tabs };
     int slot = CHUNK;
@@ -1314,8 +1289,6 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             // dword 6 = mode, kind, c_idx, ref_idx: enough to pass over the other wave's commands
             const uint32_t w6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + 6);
             if ((((w6 >> 16) & 0xff) > 0) != (role == 1)) {
-                if (((w6 >> 8) & 0xff) == VVC355_RECON_MARK)
-                    n_luma_seen++;              // the chroma wave keeps count of the luma areas recorded so far (CCLM's availability reads that list)
                 if (role == 0)
                     recon_luma_done_set(L, (int)k + 1);
                 continue;
@@ -1327,12 +1300,12 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         }
         const unsigned long long t_cmd = RPROF_NOW();
         if (c.kind == VVC355_RECON_MARK) {
-            // add_reconstructed_area (vvc_intra.c:188-206)
-            const int ch = c.c_idx > 0, hs = ch ? f.hs : 0, vs = ch ? f.vs : 0;
-            if (n_own < 1024) {
-                L.ras[ch][n_own] = recon_area_pack((c.x0 - cx.ox) >> hs, (c.y0 - cx.oy) >> vs, c.w >> hs, c.h >> vs);
-                n_own++;
-            }
+            // add_reconstructed_area (vvc_intra.c:188-206): lanes 0-31 set the unit rows, lanes 32-63 the unit columns
+            const int ux = (c.x0 - cx.ox) >> 2, uy = (c.y0 - cx.oy) >> 2, uw = max(1, c.w >> 2), uh = max(1, c.h >> 2);
+            const int i = tid & 31, t = tid >> 5;
+            const int span = t ? uw : uh, first = t ? ux : uy, len = t ? uh : uw, at = t ? uy : ux;
+            if (i < span)
+                L.rmap[role][t][first + i] |= (len >= 32 ? ~0u : ((1u << len) - 1)) << at;
             group_sync<64>();
         } else if (c.kind == VVC355_RECON_PRED) {
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
@@ -1341,8 +1314,8 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             j.x = (int16_t)x; j.y = (int16_t)y; j.w = (int16_t)w; j.h = (int16_t)h;
             j.mode = (int16_t)wide_angle_mode(c.isp_split, c_idx, w, h, c.cb_width, c.cb_height, c.mode);
             j.cb_width = c.cb_width; j.cb_height = c.cb_height;
-            j.left_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_own, c.cu_y0, x, y, 16384, c_idx, tid));
-            j.top_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_own, c.cu_x0, x, y, 16384, c_idx, tid));
+            j.left_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, x, y, 16384, c_idx));
+            j.top_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, x, y, 16384, c_idx));
             j.c_idx = (uint8_t)c_idx; j.ref_idx = c_idx ? 0 : c.ref_idx;
             j.is_mip = c.is_mip; j.mip_mode = c.mip_mode; j.mip_transposed = c.mip_transposed;
             j.isp_split = c.isp_split; j.bdpcm_flag = c.bdpcm_flag;
@@ -1364,11 +1337,11 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             group_sync<64>();
             vvc355_cclm_job j = {};
             j.x0 = c.x0; j.y0 = c.y0; j.width = c.w; j.height = c.h;
-            j.top_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_own, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1, tid));
-            j.left_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_own, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1, tid));
+            j.top_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1));
+            j.left_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1));
             j.mode = (uint8_t)c.mode; j.hs = f.hs; j.vs = f.vs;
-            j.avail_t = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, n_luma_seen, c.cu_x0, c.x0, c.y0, 1, 0, tid)) != 0);
-            j.avail_l = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, n_luma_seen, c.cu_y0, c.x0, c.y0, 1, 0, tid)) != 0);
+            j.avail_t = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, c.x0, c.y0, 1, 0)) != 0);
+            j.avail_l = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, c.x0, c.y0, 1, 0)) != 0);
             j.collocated = f.collocated;
             j.ctu_boundary = (c.y0 & ctb_mask) == 0;
             StripRef s0 = st0, s1 = st1, s2 = st2;
@@ -1416,7 +1389,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     }
     RPROF_ADD(3 + 32 * role, t_loop);
 #ifdef VVC355_RECON_PROF
-    atomicAdd(&vvc355_recon_prof[7 + 32 * role], tid == 0 ? (unsigned long long)(clock64() - c_loop) : 0ull);
+    { unsigned long long *p_ = rprof_lds(); p_[7 + 32 * role] = p_[7 + 32 * role] + (unsigned long long)(clock64() - c_loop); }
 #endif
     const unsigned long long t_join = RPROF_NOW();
     __syncthreads();
@@ -1487,8 +1460,17 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
             t32[i] = gld<uint32_t>(g);
         }
     }
+#ifdef VVC355_RECON_PROF
+    rprof_lds()[threadIdx.x & 63] = 0;
+    __syncthreads();
+#endif
     while (recon_one_ctu<BD, TILE>(f, L, tiles, role, tid)) {
     }
+#ifdef VVC355_RECON_PROF
+    __syncthreads();
+    if (role == 0)
+        atomicAdd(&vvc355_recon_prof[tid], rprof_lds()[tid]);
+#endif
 }
 
 } // namespace vvc355
