@@ -37,21 +37,33 @@ static constexpr int kEdgeLen = 6 * 64 + 5;
 
 // ------------------------------------------------------------------------------------------------ mode helpers (host + device)
 
-__host__ __device__ inline int intra_pred_angle(int mode)
+// intraPredAngle and invAngle = round(16384 / intraPredAngle) of a directional mode, one packed table entry (angle | inv << 16).
+// The reference rounds a float quotient (vvc_intra.c:683-690); no quotient of the 30 table angles is within float error of a half,
+// so the integer form is exact (tests/test_oracle_cpu.py checks all of them).
+__host__ __device__ inline uint32_t intra_angle_entry(int aidx)
 {
-    const int angles[31] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29,
-                             32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512 };
-    const int idx = mode > 34 ? mode - 50 : mode > 0 ? 18 - mode : 16 - mode;
-    return idx < 0 ? -angles[-idx] : angles[idx];
+#define VVC355_AI(a) ((uint32_t)(a) | (uint32_t)((16384 + (a) / 2) / (a)) << 16)
+    const uint32_t tab[32] = { 0, VVC355_AI(1), VVC355_AI(2), VVC355_AI(3), VVC355_AI(4), VVC355_AI(6), VVC355_AI(8), VVC355_AI(10), VVC355_AI(12),
+                               VVC355_AI(14), VVC355_AI(16), VVC355_AI(18), VVC355_AI(20), VVC355_AI(23), VVC355_AI(26), VVC355_AI(29), VVC355_AI(32),
+                               VVC355_AI(35), VVC355_AI(39), VVC355_AI(45), VVC355_AI(51), VVC355_AI(57), VVC355_AI(64), VVC355_AI(73), VVC355_AI(86),
+                               VVC355_AI(102), VVC355_AI(128), VVC355_AI(171), VVC355_AI(256), VVC355_AI(341), VVC355_AI(512), 0 };
+#undef VVC355_AI
+    return tab[aidx];
 }
-// round(16384 / angle): the reference rounds a float quotient (vvc_intra.c:683-690); no quotient of the 30 table angles is
-// within float error of a half, so the integer form is exact (tests/test_oracle_cpu.py checks all of them)
-__host__ __device__ inline int intra_inv_angle(int angle)
+__host__ __device__ inline int intra_angle_index(int mode) { return mode > 34 ? mode - 50 : mode > 0 ? 18 - mode : 16 - mode; }
+__host__ __device__ inline void intra_angle_split(int idx, uint32_t e, int *angle, int *inv)
 {
-    const int a = angle < 0 ? -angle : angle;
-    const int r = (16384 + a / 2) / a;
-    return angle < 0 ? -r : r;
+    const int a = (int)(e & 0xffff), r = (int)(e >> 16);
+    *angle = idx < 0 ? -a : a;
+    *inv = idx < 0 ? -r : r;
 }
+__host__ __device__ inline void intra_angle_inv(int mode, int *angle, int *inv)
+{
+    const int idx = intra_angle_index(mode);
+    intra_angle_split(idx, intra_angle_entry(idx < 0 ? -idx : idx), angle, inv);
+}
+__host__ __device__ inline int intra_pred_angle(int mode) { int a, r; intra_angle_inv(mode, &a, &r); return a; }
+__host__ __device__ inline int intra_inv_angle_of_mode(int mode) { int a, r; intra_angle_inv(mode, &a, &r); return r; }
 __host__ __device__ inline int ilog2i(int v)
 {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -64,7 +76,7 @@ __host__ __device__ inline int intra_nscale(int w, int h, int mode)
 {
     if (mode == 0 || mode == 1 || mode == 18 || mode == 50)
         return (ilog2i(w) + ilog2i(h) - 2) >> 2;
-    const int inv = intra_inv_angle(intra_pred_angle(mode));
+    const int inv = intra_inv_angle_of_mode(mode);
     const int side = mode >= 50 ? h : w;
     const int v = ilog2i(side) - ilog2i(3 * inv - 2) + 8;
     return v < 2 ? v : 2;
@@ -78,10 +90,13 @@ __host__ __device__ inline int intra_need_pdpc(int w, int h, int bdpcm_flag, int
     }
     return 0;
 }
+// the modes whose reference samples get the [1 2 1] filter (:450): -14 -12 -10 -6 0 2 34 66 72 76 78 80, as a bit test on mode + 14
 __host__ __device__ inline bool ref_filter_mode(int mode)
 {
-    return mode == -14 || mode == -12 || mode == -10 || mode == -6 || mode == 0 || mode == 2 || mode == 34 ||
-           mode == 66 || mode == 72 || mode == 76 || mode == 78 || mode == 80;
+    const unsigned m = (unsigned)(mode + 14);
+    const unsigned long long lo = (1ull << 0) | (1ull << 2) | (1ull << 4) | (1ull << 8) | (1ull << 14) | (1ull << 16) | (1ull << 48);
+    const unsigned long long hi = (1ull << (80 - 64)) | (1ull << (86 - 64)) | (1ull << (90 - 64)) | (1ull << (92 - 64)) | (1ull << (94 - 64));
+    return m < 64 ? (lo >> m) & 1 : m < 95 ? (hi >> (m - 64)) & 1 : false;
 }
 
 // reference-sample accessors: pixel-typed global arrays (leaf slots) or uint16 LDS arrays (flattened intra_pred)
@@ -101,6 +116,8 @@ template <int BD> struct GPix {
     __device__ __forceinline__ int ld(ptrdiff_t off) const { return ld_px<BD>(p, off); }
     __device__ __forceinline__ void st(ptrdiff_t off, int v) const { st_px<BD>(p, off, v); }
     __device__ __forceinline__ GPix at(ptrdiff_t off) const { return GPix{ p + off * (ptrdiff_t)sizeof(typename Px<BD>::type) }; }
+    __device__ __forceinline__ void st4(ptrdiff_t off, int a, int b, int c, int d) const { st(off, a); st(off + 1, b); st(off + 2, c); st(off + 3, d); }
+    __device__ __forceinline__ void ld4(ptrdiff_t off, int *v) const { v[0] = ld(off); v[1] = ld(off + 1); v[2] = ld(off + 2); v[3] = ld(off + 3); }
 };
 // The rows above a CTU as the RECON stage driver keeps them in LDS (kApr rows of their own, reaching one CTU to the right for the
 // above-right references), or nothing.  `on`: this block's top edge is the CTU's top edge, so every sample above it comes from here.
@@ -119,6 +136,20 @@ struct LPix {
     __device__ __forceinline__ int ld(int off) const { return p[base + off]; }
     __device__ __forceinline__ void st(int off, int v) const { p[base + off] = (uint16_t)v; }
     __device__ __forceinline__ LPix at(int off) const { return LPix{ p, base + off }; }
+    // four samples of one row; the tile keeps every block's first column on an even sample index (4:2:0 chroma blocks start on even
+    // columns), so two dword stores
+    __device__ __forceinline__ void st4(int off, int a, int b, int c, int d) const
+    {
+        uint32_t *q = (uint32_t *)(p + base + off);
+        q[0] = (uint32_t)a | ((uint32_t)b << 16);
+        q[1] = (uint32_t)c | ((uint32_t)d << 16);
+    }
+    __device__ __forceinline__ void ld4(int off, int *v) const
+    {
+        const uint32_t *q = (const uint32_t *)(p + base + off);
+        const uint32_t a = q[0], b = q[1];
+        v[0] = (int)(a & 0xffff); v[1] = (int)(a >> 16); v[2] = (int)(b & 0xffff); v[3] = (int)(b >> 16);
+    }
 };
 
 // component c's accessor out of three, chosen field by field (a conditional expression on the whole struct would be taken through
@@ -134,10 +165,12 @@ __device__ __forceinline__ StripRef pick3(int c, StripRef a, StripRef b, StripRe
 // latency), or from a copy the RECON stage driver keeps in LDS (one wave walks a dependent chain there: every global round trip
 // is on the critical path)
 struct IntraTabsLds {
+    uint32_t angle_inv[32];              // intra_angle_entry
     uint32_t luma_filter[64];            // fC[32] then fG[32], four int8 taps per entry
     uint8_t mip4[1024], mip8[1024], mip16[2688];
 };
 struct GTabs {
+    __device__ __forceinline__ uint32_t angle_inv(int aidx) const { return intra_angle_entry(aidx); }
     __device__ __forceinline__ uint32_t filt4(int e) const { uint32_t d; __builtin_memcpy(&d, i_tab_intra_luma_filter + e * 4, 4); return d; }
     __device__ __forceinline__ const uint8_t *mip(int size_id) const
     {
@@ -146,6 +179,7 @@ struct GTabs {
 };
 struct LTabs {
     const IntraTabsLds *t;
+    __device__ __forceinline__ uint32_t angle_inv(int aidx) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)t->angle_inv[aidx]); }
     __device__ __forceinline__ uint32_t filt4(int e) const { return t->luma_filter[e]; }
     __device__ __forceinline__ const uint8_t *mip(int size_id) const { return size_id == 0 ? t->mip4 : size_id == 1 ? t->mip8 : t->mip16; }
 };
@@ -240,7 +274,7 @@ __device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, 
     const int angle = intra_pred_angle(mode);
     int inv = 0, nscale = 0;
     if (need_pdpc) {
-        inv = intra_inv_angle(angle);
+        inv = intra_inv_angle_of_mode(mode);
         nscale = intra_nscale(w, h, mode);
     }
     const int base = -(1 + ref_idx), lw = ilog2i(w);
@@ -263,6 +297,140 @@ __device__ void pred_angular(int tid, PX src, int stride, R top, R left, int w, 
             }
         }
         src.st(x + __mul24(stride, y), pred);
+    }
+}
+
+// ---- the same predictors four samples per lane and step (w >= 4): one row's four neighbours share the row's weights and, for the
+// directional modes, the reference window (seven samples feed four 4-tap outputs), and the planar / DC / vertical / horizontal
+// PDPC (:654-682) is applied in registers before the store instead of in a second pass over the block.  A single wave walking a
+// CTU's blocks in order (the RECON stage driver) is bound by its instruction count, not by lanes.
+// pdpc_mode: -1 = none, else the prediction mode (0, 1, 18, 50) whose position-dependent weights apply
+template <int BD, typename R>
+__device__ __forceinline__ int pdpc_simple(int val, int x, int y, int pdpc_mode, int scale, R top, R left, int tl_top, int tl_left)
+{
+    int l, t, wl, wt;
+    if (pdpc_mode == 0 || pdpc_mode == 1) {
+        l = left(y); t = top(x);
+        wl = 32 >> min((x << 1) >> scale, 31);
+        wt = 32 >> min((y << 1) >> scale, 31);
+    } else {
+        l = left(y) - tl_left + val; t = top(x) - tl_top + val;
+        wl = pdpc_mode == 50 ? 32 >> min((x << 1) >> scale, 31) : 0;
+        wt = pdpc_mode == 18 ? 32 >> min((y << 1) >> scale, 31) : 0;
+    }
+    return clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6));
+}
+
+// kind: 0 planar, 1 DC (dc = the mean), 2 vertical, 3 horizontal; V = samples per lane and step (4: w >= 4; 1: any block)
+template <int BD, int NT, int V, typename R, typename PX>
+__device__ void pred_simple_q(int tid, PX src, int stride, R top, R left, int w, int h, int kind, int dc, int pdpc_mode)
+{
+    constexpr int LV = V == 4 ? 2 : 0;
+    const int lw = ilog2i(w), lh = ilog2i(h), lq = lw - LV, scale = (lw + lh - 2) >> 2;
+    const int tw = kind == 0 ? top(w) : 0, lhh = kind == 0 ? left(h) : 0;
+    const int tl_top = pdpc_mode >= 18 ? top(-1) : 0, tl_left = pdpc_mode >= 18 ? left(-1) : 0;
+    for (int q = tid; q < (h << lq); q += NT) {
+        const int y = q >> lq, x0 = (q & ((1 << lq) - 1)) << LV;
+        int v[V];
+        const int l = (kind == 0 || kind == 3) ? left(y) : 0;
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            const int x = x0 + e;
+            if (kind == 0) {
+                const int pv = ((h - 1 - y) * top(x) + (y + 1) * lhh) << lw;
+                const int ph = ((w - 1 - x) * l + (x + 1) * tw) << lh;
+                v[e] = (pv + ph + w * h) >> (lw + lh + 1);
+            } else if (kind == 1)
+                v[e] = dc;
+            else if (kind == 2)
+                v[e] = top(x);
+            else
+                v[e] = l;
+            if (pdpc_mode >= 0)
+                v[e] = pdpc_simple<BD>(v[e], x, y, pdpc_mode, scale, top, left, tl_top, tl_left);
+        }
+        if constexpr (V == 4)
+            src.st4(x0 + __mul24(stride, y), v[0], v[1], v[2], v[3]);
+        else
+            src.st(x0 + __mul24(stride, y), v[0]);
+    }
+}
+
+// directional modes: lanes own four samples ALONG the main reference (a row's four for the vertical modes, a column's four for the
+// horizontal ones): they share the row's (column's) offset and fraction, and seven reference samples cover their four windows
+template <int BD, int NT, int V, typename R, typename PX, typename TB>
+__device__ void pred_angular_q(int tid, PX src, int stride, R top, R left, int w, int h, bool vertical,
+                               int c_idx, int angle, int inv, int nscale, int ref_idx, int filter_flag, int need_pdpc, TB tabs)
+{
+    constexpr int LV = V == 4 ? 2 : 0;
+    const int base = -(1 + ref_idx);
+    const int n_along = vertical ? w : h, n_across = vertical ? h : w;
+    const int lq = ilog2i(n_along) - LV, lw = ilog2i(w);
+    const R ref = vertical ? top : left, side = vertical ? left : top;
+    const int pd_lim = need_pdpc ? (vertical ? min(w, 3 << nscale) : (3 << nscale)) : 0;
+    for (int q = tid; q < (n_across << lq); q += NT) {
+        // V = 4, vertical: q walks rows of quads (stores are 4-sample row pieces); horizontal: consecutive lanes take consecutive
+        // columns.  V = 1: q is the sample's raster index, whatever the direction (row stores stay contiguous).
+        int across, a0;
+        if (V == 4) {
+            across = vertical ? q >> lq : q & (n_across - 1);
+            a0 = vertical ? (q & ((1 << lq) - 1)) << 2 : (q >> ilog2i(n_across)) << 2;
+        } else {
+            const int y = q >> lw, x = q & (w - 1);
+            across = vertical ? y : x;
+            a0 = vertical ? x : y;
+        }
+        const int pos = (1 + ref_idx + across) * angle;
+        const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
+        const int b = base + a0 + idx;
+        int v[V];
+        if (!fact && (c_idx || !filter_flag)) {
+#pragma unroll
+            for (int e = 0; e < V; e++) v[e] = ref(b + 1 + e);
+        } else if (!c_idx) {
+            const int f = (int)tabs.filt4(filter_flag * 32 + fact);
+            const int f0 = (int)(int8_t)f, f1 = (int)(int8_t)(f >> 8), f2 = (int)(int8_t)(f >> 16), f3 = f >> 24;
+            int r[V + 3];
+#pragma unroll
+            for (int e = 0; e < V + 3; e++) r[e] = ref(b + e);
+#pragma unroll
+            for (int e = 0; e < V; e++) v[e] = clip_px<BD>((r[e] * f0 + r[e + 1] * f1 + r[e + 2] * f2 + r[e + 3] * f3 + 32) >> 6);
+        } else {
+            int r[V + 1];
+#pragma unroll
+            for (int e = 0; e < V + 1; e++) r[e] = ref(b + 1 + e);
+#pragma unroll
+            for (int e = 0; e < V; e++) v[e] = ((32 - fact) * r[e] + fact * r[e + 1] + 16) >> 5;
+        }
+        if (need_pdpc) {
+            if (vertical) {
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    const int x = a0 + e;
+                    if (x < pd_lim) {
+                        const int l = side(across + ((256 + (x + 1) * inv) >> 9));
+                        v[e] = clip_px<BD>(v[e] + (((l - v[e]) * (32 >> ((x << 1) >> nscale)) + 32) >> 6));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    const int y = a0 + e;
+                    if (y < pd_lim) {
+                        const int t = side(across + ((256 + (y + 1) * inv) >> 9));
+                        v[e] = clip_px<BD>(v[e] + (((t - v[e]) * (32 >> min(31, (y * 2) >> nscale)) + 32) >> 6));
+                    }
+                }
+            }
+        }
+        if (V == 1)
+            src.st(vertical ? a0 + __mul24(stride, across) : across + __mul24(stride, a0), v[0]);
+        else if (vertical)
+            src.st4(a0 + __mul24(stride, across), v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; e++) src.st(across + __mul24(stride, a0 + e), v[e]);
+        }
     }
 }
 
@@ -369,46 +537,66 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
     const int w = j.w, h = j.h, c_idx = j.c_idx, mode = j.mode, ref_idx = j.ref_idx;
     const bool is_mip = j.is_mip, no_isp = !j.isp_split;
     const PX src = plane.at(__mul24(j.y, stride) + j.x);
-    const int need_pdpc = intra_need_pdpc(w, h, j.bdpcm_flag, mode, ref_idx);
+    const bool directional = !is_mip && mode != 0 && mode != 1 && mode != 50 && mode != 18;
+    int angle = 0, inv = 0, nscale = 0, need_pdpc = 0;
+    if (directional) {
+        const int aidx = intra_angle_index(mode);
+        intra_angle_split(aidx, tabs.angle_inv(aidx < 0 ? -aidx : aidx), &angle, &inv);
+    }
+    if (w >= 4 && h >= 4 && !ref_idx && !j.bdpcm_flag) {        // intra_need_pdpc with the angle already at hand
+        if (!directional)
+            need_pdpc = 1;
+        else if (!(mode > 18 && mode < 50)) {
+            nscale = min(2, ilog2i(mode >= 50 ? h : w) - ilog2i(3 * inv - 2) + 8);
+            need_pdpc = nscale >= 0;
+        }
+    }
     uint16_t *left = arr[0] + kEdgeOrg, *top = arr[1] + kEdgeOrg, *fleft = arr[2] + kEdgeOrg, *ftop = arr[3] + kEdgeOrg;
 
     const bool rff = is_mip ? false : ref_filter_mode(mode);
     const bool smooth = !ref_idx && w * h > 32 && !c_idx && no_isp && rff;
     const int ref_line = ref_idx == 3 ? -4 : -1 - ref_idx;
-    int left_size, top_size, uleft, utop, refw = 0, refh = 0, angle = 0, inv = 0;
+    int left_size, top_size, uleft, utop, refw = 0, refh = 0;
     if (is_mip || mode == 0)      { left_size = h + 1; top_size = w + 1; uleft = left_size + smooth; utop = top_size + smooth; }
     else if (mode == 1)           { uleft = left_size = h; utop = top_size = w; }
     else if (mode == 50)          { uleft = left_size = need_pdpc ? h : 1; utop = top_size = w; }
     else if (mode == 18)          { uleft = left_size = h; utop = top_size = need_pdpc ? w : 1; }
     else {
         if (no_isp || c_idx) { refw = w * 2; refh = h * 2; } else { refw = j.cb_width + w; refh = j.cb_height + h; }
-        angle = intra_pred_angle(mode);
-        inv = intra_inv_angle(angle);
         utop = top_size = refw; uleft = left_size = refh;
     }
     const int la = min(uleft, (int)j.left_avail), ta = min(utop, (int)j.top_avail);
     const int prof_o = c_idx ? 32 : 0; (void)prof_o;
     unsigned long long t_ph = RPROF_NOW();
 #define RPHASE(slot) do { RPROF_ADD((slot) + prof_o, t_ph); t_ph = RPROF_NOW(); } while (0)
-#define GETP(x, y) src.ld((x) + __mul24(stride, (y)))
-    for (int i = tid; i < la; i += NT) left[i] = (uint16_t)GETP(ref_line, i);
-    for (int i = tid; i < ta; i += NT) top[i] = (uint16_t)(sr.on ? sr.at(j.x + i, ref_line) : GETP(i, ref_line));
-    // the corner samples -1 .. ref_line (at most four) go out with the edge loads, on the last lanes of the group
-    if (j.cand_up_left && tid >= NT + ref_line) {
-        const int i = tid - NT;
-        left[i] = (uint16_t)(sr.on ? sr.at(j.x + ref_line, i) : GETP(ref_line, i));
-        top[i] = (uint16_t)(sr.on ? sr.at(j.x + i, ref_line) : GETP(i, ref_line));
-    }
-    group_sync<NT>();
-    if (!j.cand_up_left && tid < -ref_line) {
-        const int i = -1 - tid;
-        left[i] = top[i] = la ? left[0] : ta ? top[0] : (uint16_t)(1 << (BD - 1));
-    }
-    group_sync<NT>();
+    // Reference samples (:467-592) in one pass.  Entry i of the left column (i = ref_line .. uleft - 1) and of the top row
+    // (i = ref_line .. utop - 1) each come from exactly one picture sample: the sample itself where it is available, the last
+    // available one of its side past the end, the corner for an empty side, and — when the corner is not available — the nearest
+    // available sample of the other side (or mid-grey): the substitution process, resolved per entry instead of by passes.
     {
-        const uint16_t tfill = top[ta - 1], lfill = left[la - 1];
-        for (int i = ta + tid; i < utop; i += NT) top[i] = tfill;
-        for (int i = la + tid; i < uleft; i += NT) left[i] = lfill;
+        const int R = -ref_line, n_left = uleft + R, total = n_left + utop + R;
+        const int mid = 1 << (BD - 1);
+        for (int e = tid; e < total; e += NT) {
+            const bool is_top = e >= n_left;
+            const int i = (is_top ? e - n_left : e) - R;
+            const int avail = is_top ? ta : la;
+            const int ie = i >= 0 ? min(i, avail - 1) : i;            // -1 past the end of an empty side: the corner
+            int sx, sy;
+            bool grey = false;
+            if (ie >= 0 || j.cand_up_left) {
+                sx = is_top ? ie : ref_line; sy = is_top ? ref_line : ie;
+            } else if (la) {
+                sx = ref_line; sy = 0;
+            } else if (ta) {
+                sx = 0; sy = ref_line;
+            } else {
+                sx = sy = 0; grey = true;
+            }
+            int v = mid;
+            if (!grey)
+                v = (sr.on && sy < 0) ? sr.at(j.x + sx, sy) : src.ld(sx + __mul24(stride, sy));
+            (is_top ? top : left)[i] = (uint16_t)v;
+        }
     }
     group_sync<NT>();
     RPHASE(22);
@@ -423,69 +611,66 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         left = fleft; top = ftop;
     }
     int filter_flag = 0;
-    if (!is_mip && mode != 0 && mode != 1) {
+    if (directional) {
         if (!(rff || ref_idx || !no_isp)) {
-            const int thres[5] = { 24, 14, 2, 0, 0 };
+            const int ti = max(0, ((ilog2i(w) + ilog2i(h)) >> 1) - 2);           // thresholds 24, 14, 2, 0, 0
             const int dist = min(abs(mode - 50), abs(mode - 18));
-            filter_flag = dist > thres[max(0, ((ilog2i(w) + ilog2i(h)) >> 1) - 2)];
+            filter_flag = dist > (ti == 0 ? 24 : ti == 1 ? 14 : ti == 2 ? 2 : 0);
         }
-        if (mode != 50 && mode != 18) {
-            if (mode >= 34) {
-                if (angle < 0) {
-                    uint16_t *p = top - (ref_idx + 1);
-                    for (int x = -h + tid; x < 0; x += NT)
-                        p[x] = left[-1 - ref_idx + min((x * inv + 256) >> 9, h)];
-                } else {
-                    const uint16_t v = top[refw - 1];
-                    for (int i = refw + tid; i <= refw + max(1, w / h) * ref_idx + 1; i += NT) top[i] = v;
-                }
+        if (mode >= 34) {
+            if (angle < 0) {
+                uint16_t *p = top - (ref_idx + 1);
+                for (int x = -h + tid; x < 0; x += NT)
+                    p[x] = left[-1 - ref_idx + min((x * inv + 256) >> 9, h)];
             } else {
-                if (angle < 0) {
-                    uint16_t *p = left - (ref_idx + 1);
-                    for (int x = -w + tid; x < 0; x += NT)
-                        p[x] = top[-1 - ref_idx + min((x * inv + 256) >> 9, w)];
-                } else {
-                    const uint16_t v = left[refh - 1];
-                    for (int i = refh + tid; i <= refh + max(1, h / w) * ref_idx + 1; i += NT) left[i] = v;
-                }
+                const uint16_t v = top[refw - 1];
+                for (int i = refw + tid; i <= refw + max(1, w / h) * ref_idx + 1; i += NT) top[i] = v;
             }
-            group_sync<NT>();
+        } else {
+            if (angle < 0) {
+                uint16_t *p = left - (ref_idx + 1);
+                for (int x = -w + tid; x < 0; x += NT)
+                    p[x] = top[-1 - ref_idx + min((x * inv + 256) >> 9, w)];
+            } else {
+                const uint16_t v = left[refh - 1];
+                for (int i = refh + tid; i <= refh + max(1, h / w) * ref_idx + 1; i += NT) left[i] = v;
+            }
         }
+        group_sync<NT>();
     }
 
     RPHASE(23);
     LRef T{ top }, L{ left };
-    if (is_mip)          pred_mip<BD, NT>(tid, src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch, tabs);
-    else if (mode == 0)  pred_planar<BD, NT>(tid, src, stride, T, L, w, h);
-    else if (mode == 1)  pred_dc<BD, NT>(tid, src, stride, T, L, w, h, scratch);
-    else if (mode == 50) pred_vh<BD, NT>(tid, src, stride, T, w, h, true);
-    else if (mode == 18) pred_vh<BD, NT>(tid, src, stride, L, w, h, false);
-    else                 pred_angular<BD, NT>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, mode, ref_idx, filter_flag, need_pdpc, tabs);
-
-    RPHASE(24);
-    if (need_pdpc && !is_mip && (mode == 0 || mode == 1 || mode == 50 || mode == 18)) {      // :654-682
-        group_sync<NT>();
-        const int scale = (ilog2i(w) + ilog2i(h) - 2) >> 2;
-        const int lw = ilog2i(w);
-        for (int i = tid; i < w * h; i += NT) {
-            const int y = i >> lw, x = i & (w - 1);
-            const int val = GETP(x, y);
-            int l, t, wl, wt;
-            if (mode == 0 || mode == 1) {
-                l = left[y]; t = top[x];
-                wl = 32 >> min((x << 1) >> scale, 31);
-                wt = 32 >> min((y << 1) >> scale, 31);
-            } else {
-                l = left[y] - left[-1] + val; t = top[x] - top[-1] + val;
-                wl = mode == 50 ? 32 >> min((x << 1) >> scale, 31) : 0;
-                wt = mode == 18 ? 32 >> min((y << 1) >> scale, 31) : 0;
-            }
-            src.st(x + __mul24(stride, y), clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6)));
-        }
+    if (is_mip) {
+        pred_mip<BD, NT>(tid, src, stride, T, L, w, h, j.mip_mode, j.mip_transposed, scratch, tabs);
+        RPHASE(24);
+        return;
     }
-    RPHASE(25);
+    // four samples per lane once one-per-lane would take three or more steps (the wave's time is its longest lane's instruction count) and the
+    // block has whole groups of four along the store direction; one sample per lane otherwise.  PDPC is applied before the store.
+    const bool quads = w * h > 2 * NT && w >= 4 && (!directional || mode >= 34 || h >= 4);
+    if (directional) {
+        if (quads) pred_angular_q<BD, NT, 4>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, angle, inv, nscale, ref_idx, filter_flag, need_pdpc, tabs);
+        else       pred_angular_q<BD, NT, 1>(tid, src, stride, T, L, w, h, mode >= 34, c_idx, angle, inv, nscale, ref_idx, filter_flag, need_pdpc, tabs);
+    } else {
+        int dc = 0;
+        if (mode == 1) {
+            int part = 0;
+            if (w >= h) for (int i = tid; i < w; i += NT) part += T(i);
+            if (w <= h) for (int i = tid; i < h; i += NT) part += L(i);
+            const unsigned offset = w == h ? (unsigned)w << 1 : (unsigned)max(w, h);
+            dc = (group_sum<NT>(part, tid, scratch) + (int)(offset >> 1)) >> ilog2i((int)offset);
+        }
+        const int kind = mode == 0 ? 0 : mode == 1 ? 1 : mode == 50 ? 2 : 3;
+        // DC and horizontal stores cover whole groups of four columns (:856, :885): blocks narrower than four take the leaf routines
+        if (w < 4 && (kind == 1 || kind == 3)) {
+            if (kind == 1) pred_dc<BD, NT>(tid, src, stride, T, L, w, h, scratch);
+            else           pred_vh<BD, NT>(tid, src, stride, L, w, h, false);
+        } else if (quads) pred_simple_q<BD, NT, 4>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc ? mode : -1);
+        else              pred_simple_q<BD, NT, 1>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc ? mode : -1);
+    }
+    RPHASE(24);
 #undef RPHASE
-#undef GETP
 }
 
 template <int BD, int NT>
@@ -549,7 +734,7 @@ static void slot_leaf(int bd, int kind, uint8_t *src, const uint8_t *top, const 
         angular_main_range(vertical ? w : h, vertical ? h : w, c_idx, mode, ref_idx, filter_flag, &lo, &hi);
         if (vertical) { t_lo = lo; t_hi = hi; } else { l_lo = lo; l_hi = hi; }
         if (need_pdpc) {
-            const int inv = intra_inv_angle(intra_pred_angle(mode)), nscale = intra_nscale(w, h, mode);
+            const int inv = intra_inv_angle_of_mode(mode), nscale = intra_nscale(w, h, mode);
             int slo = 1 << 30, shi = -(1 << 30);
             const int n_side = vertical ? h : w, n_pd = vertical ? (w < (3 << nscale) ? w : (3 << nscale)) : (h < (3 << nscale) ? h : (3 << nscale));
             for (int k = 0; k < n_pd; k++) {
@@ -1276,6 +1461,8 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     uint16_t (*arr)[kEdgeLen] = L.arr[role];
     const LTabs tabs{ &L.tabs };
     int slot = CHUNK;
+    int4 pre[4] = {};                    // residuals fetched one command ahead (the first 1024 of the block)
+    int pre_k = -1;
     for (uint32_t k = 0; k < ctu.n_cmd; k++) {
         if (slot == CHUNK) {
             slot = 0;
@@ -1284,6 +1471,22 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         }
         const int lane0 = slot * CMD_DW;
         slot++;
+        // the next command, when it is in this chunk and a residual block of this wave: start its first loads now, so that they
+        // travel while the current command (usually that block's prediction) runs
+        if (slot < CHUNK && k + 1 < ctu.n_cmd) {
+            const int ln = slot * CMD_DW;
+            const uint32_t n6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 6);
+            if (((n6 >> 8) & 0xff) == VVC355_RECON_RESID && ((((n6 >> 16) & 0xff) > 0) == (role == 1))) {
+                const uint64_t ptr = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 1) << 32);
+                const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 3);
+                const int nn = (int)(wh & 0xffff) * (int)(wh >> 16);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (tid * 4 + 256 * u < nn)
+                        pre[u] = gld<int4>((const int *)ptr + tid * 4 + 256 * u);
+                pre_k = (int)k + 1;
+            }
+        }
         vvc355_recon_cmd c;
         {
             // dword 6 = mode, kind, c_idx, ref_idx: enough to pass over the other wave's commands
@@ -1369,17 +1572,28 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             const PX dst = pick3(c_idx, pl0, pl1, pl2).at((c.y0 >> vs) * stride + (c.x0 >> hs));
             const int *res = (const int *)c.resid;
             const int lw = ilog2i(w);
-            for (int i = tid * 4; i < n; i += 256) {          // w >= 4: four samples of one row per lane and step
-                const int4 r4 = gld<int4>(res + i);
+            const bool have = pre_k == (int)k;
+            auto add4 = [&](int i, const int4 r4) {             // w >= 4: four samples of one row per lane and step
                 int r[4] = { r4.x, r4.y, r4.z, r4.w };
                 const int o = (i >> lw) * stride + (i & (w - 1));
+                int d[4];
+                dst.ld4(o, d);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (c.joint & 1)
                         r[q] = (r[q] * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
-                    dst.st(o + q, clip_px<BD>(dst.ld(o + q) + r[q]));
+                    d[q] = clip_px<BD>(d[q] + r[q]);
                 }
+                dst.st4(o, d[0], d[1], d[2], d[3]);
+            };
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = tid * 4 + 256 * u;
+                if (i < n)
+                    add4(i, have ? pre[u] : gld<int4>(res + i));
             }
+            for (int i = tid * 4 + 1024; i < n; i += 256)
+                add4(i, gld<int4>(res + i));
             if (TILE) group_sync<64>(); else recon_sync_mem();
         }
         if (role == 0)
@@ -1450,15 +1664,17 @@ __global__ __launch_bounds__(128) void recon_wavefront_kernel(const vvc355_recon
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
     // the predictors' tables -> LDS (visible after the first CTU's barriers)
     {
-        uint32_t *t32 = (uint32_t *)&L.tabs;
+        uint32_t *t32 = (uint32_t *)&L.tabs.luma_filter[0];
         constexpr int N0 = 64, N1 = N0 + 256, N2 = N1 + 256, N3 = N2 + 672;
-        static_assert(sizeof(IntraTabsLds) == N3 * 4, "table copy covers the whole struct");
+        static_assert(sizeof(IntraTabsLds) == (32 + N3) * 4, "table copy covers the whole struct");
         for (int i = threadIdx.x; i < N3; i += 128) {
             const uint8_t *g = i < N0 ? (const uint8_t *)i_tab_intra_luma_filter + 4 * i
                              : i < N1 ? i_tab_mip_matrix_4x4 + 4 * (i - N0)
                              : i < N2 ? i_tab_mip_matrix_8x8 + 4 * (i - N1) : i_tab_mip_matrix_16x16 + 4 * (i - N2);
             t32[i] = gld<uint32_t>(g);
         }
+        if (threadIdx.x < 32)
+            L.tabs.angle_inv[threadIdx.x] = intra_angle_entry(threadIdx.x);
     }
 #ifdef VVC355_RECON_PROF
     rprof_lds()[threadIdx.x & 63] = 0;
