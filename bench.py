@@ -141,6 +141,17 @@ class Frame:
         return t.stride(0) * t.element_size()
 
 
+def ifc_mvf_dtype():
+    """The reference's MvField (vvc_ctu.h:195-202) as a numpy record."""
+    return np.dtype([("mv", "<i4", (2, 2)), ("ref_idx", "i1", (2,)), ("hpel_if_idx", "u1"), ("bcw_idx", "u1"), ("pred_flag", "u1"), ("ciip_flag", "u1"), ("pad_", "u1", (2,))])
+
+
+def ifc_pu_dtype():
+    """vvc355_inter_pu as a numpy record."""
+    return np.dtype([("x0", "<i2"), ("y0", "<i2"), ("cb_width", "<i2"), ("cb_height", "<i2"), ("num_sb_x", "u1"), ("num_sb_y", "u1"), ("dmvr_flag", "u1"),
+                     ("bdof_flag", "u1"), ("ciip_flag", "u1"), ("hpel_if_idx", "u1"), ("slice", "u1"), ("pad_", "u1"), ("first_job", "<u4")])
+
+
 def alf_filter_sets(rng, n_sets):
     """APS-like luma filter sets: 25 filters x 12 int8-range coefficients, clip indices 0..3, a random class map."""
     return [(rng.integers(-128, 128, size=(25, 12)).astype(np.int16),
@@ -213,14 +224,57 @@ def build_chain(lib, torch, fr):
         j["x"], j["y"], j["w"], j["h"] = x0 >> sh, y0 >> sh, bs >> sh, bs >> sh
         j["pic_w"], j["pic_h"] = w, h
         j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
-        j["dmvr"], j["bdof"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
+        j["dmvr"], j["bdof"] = MC_TOOLS & 1, ((MC_TOOLS >> 1) & 1) if c == 0 else 0
+        j["pred_flag"] = 3
         bj.append(j)
     # chroma jobs interleaved Cb, Cr, Cb, Cr, ...: the chroma launch predicts the two planes of a sub-block in one wave
     luma_jobs = bj[0]
     chroma_jobs = np.empty(2 * n_blk, dtype=bj[1].dtype)
     chroma_jobs[0::2], chroma_jobs[1::2] = bj[1], bj[2]
-    d_bl, d_bc = fr.upload(luma_jobs.view(np.uint8)), fr.upload(chroma_jobs.view(np.uint8))
     n_bl, n_bc = len(luma_jobs), len(chroma_jobs)
+    # The job arrays above are the host's expectation only.  What the device runs is written by vvc355_inter_frame_build from the
+    # decoder-side tables: the MvField table (one entry per 4x4 luma block), the reference picture lists, the slice's weight tables
+    # and one 20-byte record per coding unit (here: every 16x16 block is a bi-predicted coding unit of one sub-block).
+    pic_w, pic_h = fr.dims[0]
+    mvf = np.zeros((pic_h // 4 + 1, pic_w // 4), ifc_mvf_dtype())
+    for dy in range(bs // 4):
+        for dx in range(bs // 4):
+            e = mvf[y0 // 4 + dy, x0 // 4 + dx]
+            e["mv"] = mv.reshape(-1, 2, 2)
+            e["pred_flag"] = 3
+            mvf[y0 // 4 + dy, x0 // 4 + dx] = e
+    pus = np.zeros(n_blk, ifc_pu_dtype())
+    pus["x0"], pus["y0"], pus["cb_width"], pus["cb_height"] = x0, y0, bs, bs
+    pus["num_sb_x"] = pus["num_sb_y"] = 1
+    pus["dmvr_flag"], pus["bdof_flag"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
+    pus["first_job"] = np.arange(n_blk)
+    reft = (abi.RefPic * 32)()
+    for l in range(2):
+        for c in range(3):
+            reft[l * 16].plane[c] = ptr(ref[l][c]) + Frame.PAD * fr.pitch(ref[l][c]) + Frame.PAD * isz
+            reft[l * 16].stride[c] = fr.pitch(ref[l][c])
+    d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
+    d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(abi.InterSlice()), np.uint8))
+    d_bl = torch.zeros(luma_jobs.nbytes, dtype=torch.uint8, device="cuda")
+    d_bc = torch.zeros(chroma_jobs.nbytes, dtype=torch.uint8, device="cuda")
+    fr.keep += [d_bl, d_bc]
+    inf = abi.InterFrame()
+    for c in range(3):
+        inf.dst[c], inf.dst_stride[c] = ptr(rec[c]), fr.pitch(rec[c])
+    inf.mvf, inf.refs, inf.pus, inf.slices = ptr(d_mvf), ptr(d_reft), ptr(d_pus), ptr(d_slices)
+    inf.jobs_luma, inf.jobs_chroma, inf.records = ptr(d_bl), ptr(d_bc), ptr(d_rec)
+    inf.mvf_stride, inf.n_pus, inf.n_jobs = pic_w // 4, n_blk, n_blk
+    inf.width, inf.height = pic_w, pic_h
+    inf.hs, inf.vs, inf.chroma_format_idc, inf.pixel_shift = 1, 1, 1, int(isz == 2)
+    d_inf = fr.upload(np.frombuffer(bytes(inf), np.uint8))
+    fr.keep.append(inf)
+
+    def check_build(fc, orc, env):
+        got_l, got_c = env.after[ptr(d_bl)].view(luma_jobs.dtype), env.after[ptr(d_bc)].view(chroma_jobs.dtype)
+        return n_bl + n_bc, int((got_l != luma_jobs).sum() + (got_c != chroma_jobs).sum())
+
+    chain.append(Stage("inter_job_build", "inter_build_kernel", lambda st: lib.vvc355_inter_frame_build(st, ptr(d_inf), ctypes.addressof(inf)),
+                       n_blk * 3 * ctypes.sizeof(abi.BipredJob), writes=[d_bl, d_bc], check=check_build))
     inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)
 
     # luma refines the motion (DMVR) and writes the records; chroma of both planes follows at the refined motion.

@@ -120,6 +120,8 @@ BATCH_SIGNATURES = {
     "bipred_chroma_batch": ("v", "pipi"),
     "affine_batch":     ("v", "pipi"),
     "gpm_batch":        ("v", "pipi"),
+    "inter_frame_build": ("v", "ppp"),
+    "inter_frame_pass": ("v", "pipp"),
     "deblock_frame_pass": ("v", "pipp"),
     "sao_frame_pass":   ("v", "pipp"),
     "alf_frame_pass":   ("v", "pippp"),
@@ -289,6 +291,35 @@ class BipredJob(ctypes.Structure):
         ("bdof", ctypes.c_uint8), ("hf_idx", ctypes.c_uint8), ("vf_idx", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
         ("pred_flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 5),
     ]
+
+
+class RefPic(ctypes.Structure):
+    """Mirror of vvc355_ref_pic."""
+    _fields_ = [("plane", ctypes.c_uint64 * 3), ("stride", ctypes.c_int32 * 3), ("pad_", ctypes.c_int32)]
+
+
+class InterPu(ctypes.Structure):
+    """Mirror of vvc355_inter_pu."""
+    _fields_ = [("x0", ctypes.c_int16), ("y0", ctypes.c_int16), ("cb_width", ctypes.c_int16), ("cb_height", ctypes.c_int16),
+                ("num_sb_x", ctypes.c_uint8), ("num_sb_y", ctypes.c_uint8), ("dmvr_flag", ctypes.c_uint8), ("bdof_flag", ctypes.c_uint8),
+                ("ciip_flag", ctypes.c_uint8), ("hpel_if_idx", ctypes.c_uint8), ("slice", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
+                ("first_job", ctypes.c_uint32)]
+
+
+class InterSlice(ctypes.Structure):
+    """Mirror of vvc355_inter_slice."""
+    _fields_ = [("weighted_pred", ctypes.c_uint8), ("weighted_bipred", ctypes.c_uint8), ("log2_denom", ctypes.c_uint8 * 2),
+                ("weight", ctypes.c_int16 * 16 * 3 * 2), ("offset", ctypes.c_int16 * 16 * 3 * 2)]
+
+
+class InterFrame(ctypes.Structure):
+    """Mirror of vvc355_inter_frame."""
+    _fields_ = [("dst", ctypes.c_uint64 * 3), ("mvf", ctypes.c_uint64), ("refs", ctypes.c_uint64), ("pus", ctypes.c_uint64), ("slices", ctypes.c_uint64),
+                ("jobs_luma", ctypes.c_uint64), ("jobs_chroma", ctypes.c_uint64), ("records", ctypes.c_uint64),
+                ("dst_stride", ctypes.c_int32 * 3), ("mvf_stride", ctypes.c_int32), ("n_pus", ctypes.c_int32), ("n_jobs", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("chroma_format_idc", ctypes.c_uint8), ("pixel_shift", ctypes.c_uint8),
+                ("pad_", ctypes.c_uint8 * 4)]
 
 
 class GpmJob(ctypes.Structure):

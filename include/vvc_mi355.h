@@ -473,6 +473,57 @@ typedef struct vvc355_gpm_job {
 
 void vvc355_gpm_batch(void *stream, int bd, const vvc355_gpm_job *jobs_dev, int n_jobs);
 
+/* ------------------------------------------------------------------ inter prediction stage driver (inter_frame.hip) */
+
+/*
+ * Regular inter prediction of a whole picture straight from what the decoder holds after parsing, the device half of
+ * ff_vvc_predict_inter -> pred_regular_blk (vvc_inter.c:783-813): for every coding unit the sub-block walk (sbw = cb_width /
+ * num_sb_x, ...), the sub-block's motion from the MvField table (ff_vvc_get_mvf), the reference pictures of its ref_idx, the
+ * interpolation filter set of hpel_if_idx, the weights of derive_weight / derive_weight_uni (:129-177) from the slice's prediction
+ * weight table and bcw_idx, and then the fused sub-block kernels above (luma with DMVR + BDOF, chroma at the refined motion).  The
+ * job arrays are written by a kernel; the host only lists the coding units.
+ *   mvf            DEVICE MvField[] as the decoder keeps it (fc->tab.mvf: one entry per 4x4 luma block, `mvf_stride` entries per row):
+ *                  int32 mv[2][2] (x, y per list), int8 ref_idx[2], uint8 hpel_if_idx, bcw_idx, pred_flag, ciip_flag, 2 pad bytes = 24 bytes
+ *   refs           DEVICE vvc355_ref_pic[2][16]: the slice's RefPicList[list][ref_idx] planes (sample (0, 0), strides in bytes)
+ *   pus            DEVICE vvc355_inter_pu[n_pus]; first_job = running sum of the units' job counts
+ *                  num_sb_x * num_sb_y * ceil(sbw / 16) * ceil(sbh / 16): sub-blocks wider or taller than 16 (no DMVR / BDOF there,
+ *                  the reference caps those at 16) are predicted in 16x16 tiles, which is exact for plain interpolation + averaging
+ *   slices         DEVICE vvc355_inter_slice[]: per slice the weighted-prediction switches and the PredWeightTable
+ *   jobs_luma      DEVICE scratch, n_jobs entries; jobs_chroma 2 * n_jobs (Cb, Cr interleaved; unused for 4:0:0); records n_jobs
+ */
+typedef struct vvc355_ref_pic { uint64_t plane[3]; int32_t stride[3]; int32_t pad_; } vvc355_ref_pic;
+typedef struct vvc355_inter_pu {
+    int16_t  x0, y0, cb_width, cb_height;     /* luma samples */
+    uint8_t  num_sb_x, num_sb_y;              /* pu->mi.num_sb_x / _y */
+    uint8_t  dmvr_flag, bdof_flag;            /* pu->dmvr_flag, pu->bdof_flag */
+    uint8_t  ciip_flag;                       /* cu->ciip_flag: bcw weights are ignored (derive_weight :158) */
+    uint8_t  hpel_if_idx;                     /* pu->mi.hpel_if_idx */
+    uint8_t  slice;                           /* index into slices[] */
+    uint8_t  pad_;
+    uint32_t first_job;
+} vvc355_inter_pu;
+typedef struct vvc355_inter_slice {
+    uint8_t  weighted_pred, weighted_bipred;  /* IS_P && pps_weighted_pred_flag; IS_B && pps_weighted_bipred_flag */
+    uint8_t  log2_denom[2];                   /* luma, chroma */
+    int16_t  weight[2][3][16], offset[2][3][16];      /* PredWeightTable: [list][component][ref_idx] */
+} vvc355_inter_slice;
+typedef struct vvc355_inter_frame {
+    uint64_t dst[3];              /* the current picture's planes */
+    uint64_t mvf, refs, pus, slices;
+    uint64_t jobs_luma, jobs_chroma, records;
+    int32_t  dst_stride[3];       /* bytes */
+    int32_t  mvf_stride;          /* MvField entries per row (min_pu_width) */
+    int32_t  n_pus, n_jobs;
+    int32_t  width, height;       /* luma samples */
+    uint8_t  hs, vs, chroma_format_idc;
+    uint8_t  pixel_shift;         /* 0: 8-bit samples, 1: 16-bit samples (sps->pixel_shift) */
+    uint8_t  pad_[4];
+} vvc355_inter_frame;
+/* job arrays only (then vvc355_bipred_batch on jobs_luma, vvc355_bipred_chroma_batch on jobs_chroma) */
+void vvc355_inter_frame_build(void *stream, const vvc355_inter_frame *frame_dev, const vvc355_inter_frame *frame_host);
+/* build + luma + chroma */
+void vvc355_inter_frame_pass(void *stream, int bd, const vvc355_inter_frame *frame_dev, const vvc355_inter_frame *frame_host);
+
 /* ------------------------------------------------------------------ affine sub-blocks with PROF (affine.hip) */
 
 /*

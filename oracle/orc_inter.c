@@ -606,3 +606,89 @@ ORC_API void orc_affine_block(int bd, const orc_affine_job *job)
             orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], 4, 4);
     }
 }
+
+/* ---- pred_regular_blk over a list of coding units (vvc_inter.c:783-813): per unit the sub-block walk, the sub-block's MvField
+ * (ff_vvc_get_mvf), the reference pictures of its ref_idx, hpel_if_idx as the luma filter set (pred_regular_luma's hf_idx / vf_idx),
+ * derive_weight / derive_weight_uni (:129-177), one job per component; sub-blocks larger than 16x16 (neither DMVR nor BDOF there) in
+ * 16x16 tiles, which changes nothing for plain interpolation + averaging.  Then each job through orc_bipred_block, luma first. */
+ORC_API void orc_inter_frame_build(const orc_inter_frame *f)
+{
+    static const int bcw_w_lut[5] = { 4, 5, 3, 10, -2 };        /* vvc_inter.c:29 */
+    const orc_inter_pu *pus = (const orc_inter_pu *)(uintptr_t)f->pus;
+    const orc_inter_slice *slices = (const orc_inter_slice *)(uintptr_t)f->slices;
+    const orc_ref_pic *refs = (const orc_ref_pic *)(uintptr_t)f->refs;
+    const orc_mv_field *mvf_tab = (const orc_mv_field *)(uintptr_t)f->mvf;
+    orc_bipred_job *jl = (orc_bipred_job *)(uintptr_t)f->jobs_luma, *jc = (orc_bipred_job *)(uintptr_t)f->jobs_chroma;
+    orc_bipred_result *rec = (orc_bipred_result *)(uintptr_t)f->records;
+    for (int u = 0; u < f->n_pus; u++) {
+        const orc_inter_pu *pu = pus + u;
+        const orc_inter_slice *sl = slices + pu->slice;
+        const int sbw = pu->cb_width / pu->num_sb_x, sbh = pu->cb_height / pu->num_sb_y;
+        const int tw = sbw < 16 ? sbw : 16, th = sbh < 16 ? sbh : 16;
+        uint32_t job = pu->first_job;
+        for (int sby = 0; sby < pu->num_sb_y; sby++)
+            for (int sbx = 0; sbx < pu->num_sb_x; sbx++) {
+                const int sx = pu->x0 + sbx * sbw, sy = pu->y0 + sby * sbh;
+                const orc_mv_field *mv = mvf_tab + (sy >> 2) * f->mvf_stride + (sx >> 2);
+                const int bi = mv->pred_flag == 3;
+                for (int ty = 0; ty < sbh; ty += th)
+                    for (int tx = 0; tx < sbw; tx += tw, job++)
+                        for (int c = 0; c < (f->chroma_format_idc ? 3 : 1); c++) {
+                            const int hs = c ? f->hs : 0, vs = c ? f->vs : 0;
+                            const int x = (sx + tx) >> hs, y = (sy + ty) >> vs;
+                            orc_bipred_job j;
+                            memset(&j, 0, sizeof(j));
+                            j.dst = f->dst[c] + (uint64_t)y * f->dst_stride[c] + ((uint64_t)x << f->pixel_shift);
+                            j.dst_stride = f->dst_stride[c];
+                            for (int l = 0; l < 2; l++) {
+                                if (!(mv->pred_flag & (1 << l)))
+                                    continue;
+                                const orc_ref_pic *rp = refs + l * 16 + mv->ref_idx[l];
+                                if (l) { j.ref1 = rp->plane[c]; j.ref1_stride = rp->stride[c]; }
+                                else   { j.ref0 = rp->plane[c]; j.ref0_stride = rp->stride[c]; }
+                                j.mv[2 * l] = mv->mv[l][0];
+                                j.mv[2 * l + 1] = mv->mv[l][1];
+                            }
+                            j.rec = (uint64_t)(uintptr_t)(rec + job);
+                            j.x = (int16_t)x; j.y = (int16_t)y; j.w = (int16_t)(tw >> hs); j.h = (int16_t)(th >> vs);
+                            j.pic_w = (int16_t)(f->width >> hs); j.pic_h = (int16_t)(f->height >> vs);
+                            j.chroma = c > 0; j.hs = f->hs; j.vs = f->vs;
+                            j.dmvr = bi && pu->dmvr_flag;
+                            j.bdof = !c && bi && pu->bdof_flag;
+                            j.hf_idx = j.vf_idx = c ? 0 : pu->hpel_if_idx;
+                            j.pred_flag = mv->pred_flag;
+                            if (bi) {
+                                const int weight_flag = sl->weighted_pred || (sl->weighted_bipred && !pu->dmvr_flag);
+                                if ((weight_flag || mv->bcw_idx) && !(mv->bcw_idx && pu->ciip_flag)) {
+                                    j.weight_flag = 1;
+                                    if (mv->bcw_idx) {
+                                        j.denom = 2; j.w1 = (int16_t)bcw_w_lut[mv->bcw_idx]; j.w0 = (int16_t)(8 - j.w1);
+                                    } else {
+                                        j.denom = sl->log2_denom[c > 0];
+                                        j.w0 = sl->weight[0][c][mv->ref_idx[0]]; j.w1 = sl->weight[1][c][mv->ref_idx[1]];
+                                        j.o0 = sl->offset[0][c][mv->ref_idx[0]]; j.o1 = sl->offset[1][c][mv->ref_idx[1]];
+                                    }
+                                }
+                            } else if (sl->weighted_pred || sl->weighted_bipred) {
+                                const int lx = mv->pred_flag - 1;
+                                j.weight_flag = 1;
+                                j.denom = sl->log2_denom[c > 0];
+                                j.w0 = sl->weight[lx][c][mv->ref_idx[lx]];
+                                j.o0 = sl->offset[lx][c][mv->ref_idx[lx]];
+                            }
+                            if (c == 0) jl[job] = j; else jc[2 * job + c - 1] = j;
+                        }
+            }
+    }
+}
+
+ORC_API void orc_inter_frame_pass(int bd, const orc_inter_frame *f)
+{
+    orc_inter_frame_build(f);
+    const orc_bipred_job *jl = (const orc_bipred_job *)(uintptr_t)f->jobs_luma, *jc = (const orc_bipred_job *)(uintptr_t)f->jobs_chroma;
+    for (int i = 0; i < f->n_jobs; i++)
+        orc_bipred_block(bd, jl + i);
+    if (f->chroma_format_idc)
+        for (int i = 0; i < 2 * f->n_jobs; i++)
+            orc_bipred_block(bd, jc + i);
+}

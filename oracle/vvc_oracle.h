@@ -123,6 +123,32 @@ typedef struct orc_gpm_job {
 } orc_gpm_job;
 void orc_gpm_block(int bd, const orc_gpm_job *job);
 
+/* ---- regular inter prediction of a picture from the decoder's tables (orc_inter.c, "pred_regular_blk" over a list of coding units) ----
+ * Same layouts as vvc355_ref_pic / vvc355_inter_pu / vvc355_inter_slice / vvc355_inter_frame of include/vvc_mi355.h, host addresses. */
+typedef struct orc_mv_field { int32_t mv[2][2]; int8_t ref_idx[2]; uint8_t hpel_if_idx, bcw_idx, pred_flag, ciip_flag, pad_[2]; } orc_mv_field;
+typedef struct orc_ref_pic { uint64_t plane[3]; int32_t stride[3]; int32_t pad_; } orc_ref_pic;
+typedef struct orc_inter_pu {
+    int16_t  x0, y0, cb_width, cb_height;
+    uint8_t  num_sb_x, num_sb_y, dmvr_flag, bdof_flag, ciip_flag, hpel_if_idx, slice, pad_;
+    uint32_t first_job;
+} orc_inter_pu;
+typedef struct orc_inter_slice {
+    uint8_t  weighted_pred, weighted_bipred, log2_denom[2];
+    int16_t  weight[2][3][16], offset[2][3][16];
+} orc_inter_slice;
+typedef struct orc_inter_frame {
+    uint64_t dst[3];
+    uint64_t mvf, refs, pus, slices;
+    uint64_t jobs_luma, jobs_chroma, records;
+    int32_t  dst_stride[3];
+    int32_t  mvf_stride;
+    int32_t  n_pus, n_jobs;
+    int32_t  width, height;
+    uint8_t  hs, vs, chroma_format_idc, pixel_shift, pad_[4];
+} orc_inter_frame;
+void orc_inter_frame_build(const orc_inter_frame *f);
+void orc_inter_frame_pass(int bd, const orc_inter_frame *f);
+
 /* ---- one 4x4 luma sub-block of an affine coding unit incl. PROF (orc_inter.c, "luma_prof_uni / luma_prof_bi") ----
  * Same layout as vvc355_affine_job of include/vvc_mi355.h, with host addresses. */
 typedef struct orc_affine_job {
