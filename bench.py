@@ -684,8 +684,23 @@ def build_chain(lib, torch, fr):
             return len(work.order), bad
 
         intra_samples = int(sum(int(c[3]) * int(c[4]) for c in work.cmds[work.cmds["kind"] == abi.RECON_MARK] if c[11] == 0)) * 3 // 2
+        # what bounds this stage is not bandwidth but the longest chain of dependent CTUs (left, upper-left, upper, upper-right
+        # neighbours that have commands), each walked by one wave per channel type: its length in CTUs and in commands
+        ncx_ = fr.ncx if hasattr(fr, "ncx") else (fr.width + CTB - 1) // CTB
+        ncmd = work.ctus["n_cmd"].astype(np.int64)
+        depth_c, depth_k = np.zeros(len(ncmd), np.int64), np.zeros(len(ncmd), np.int64)
+        for rs in work.order:
+            rs = int(rs)
+            rx_, best_c, best_k = rs % ncx_, 0, 0
+            for d_ in ((rs - 1) if rx_ else -1, (rs - ncx_ - 1) if rx_ else -1, rs - ncx_, (rs - ncx_ + 1) if rx_ + 1 < ncx_ else -1):
+                if d_ >= 0 and ncmd[d_]:
+                    best_c, best_k = max(best_c, int(depth_c[d_])), max(best_k, int(depth_k[d_]))
+            depth_c[rs], depth_k[rs] = best_c + 1, best_k + int(ncmd[rs])
+        recon_chain = {"ctus_with_commands": int(len(work.order)), "commands": int(len(work.cmds)),
+                       "longest_dependency_chain_ctus": int(depth_c.max()), "longest_dependency_chain_commands": int(depth_k.max())}
         chain.append(Stage("intra_recon_wavefront", f"recon_wavefront_kernel<{bd}>", lambda st: lib.vvc355_recon_frame_pass(st, bd, ptr(d_rf), ctypes.addressof(rf)),
                            intra_samples * isz, writes=rec, check=check_recon))
+        chain[-1].extra = {"bound": "dependency chain (one wave per CTU and channel type), not bandwidth", **recon_chain}
 
     # ---------------------------------------------------------------- LMCS inverse luma mapping
     lut = fr.upload(np.sort(rng.integers(0, 1 << bd, size=1 << bd)).astype(np.uint8 if bd == 8 else np.uint16))
@@ -1350,7 +1365,7 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--bd", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=4, help="independent frames processed concurrently per step (one HIP stream each); 1 = latency of a single frame")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="independent frames processed concurrently per step (one HIP stream each); 1 = latency of a single frame")
     ap.add_argument("--with-upload", action="store_true", help="additionally time the steps with every per-frame descriptor copied from pinned host memory first")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
@@ -1514,6 +1529,10 @@ def main(argv=None):
             gbs = st.algorithmic_bytes / (stage_ms[st.name] * 1e-3) / 1e9
             stages[st.name] = {"kernel": st.kernel, "ms": stage_ms[st.name], "algorithmic_bytes": st.algorithmic_bytes,
                                "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+            if getattr(st, "extra", None):
+                stages[st.name].update(st.extra)
+                if "longest_dependency_chain_commands" in st.extra:
+                    stages[st.name]["us_per_command_on_the_chain"] = stage_ms[st.name] * 1e3 / max(1, st.extra["longest_dependency_chain_commands"])
         dom = next(st for st in chain if st.name == dom_name)         # the kernel the step time is dominated by
         achieved = stages[dom.name]["GB/s"]
         out = {
@@ -1553,6 +1572,10 @@ def main(argv=None):
                 "frac": achieved / HBM_PEAK_GBS,
                 "ms_per_launch": stage_ms[dom.name],
                 "algorithmic_bytes_per_launch": dom.algorithmic_bytes,
+                # the same stage of one frame running alone (the untimed single-frame pass): what the kernel reaches without the
+                # other frames in flight sharing the device
+                "isolated": {"ms_per_launch": breakdown[dom.name], "achieved": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9,
+                             "frac": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "note": ("dominant = the batched stage with the largest launch time; the in-order intra pass (intra_recon_wavefront) is a latency-bound "
                          "dependent chain on a few hundred waves that overlaps the other frames in flight — see stages / frame_latency_ms") if n_ff > 1 else "",
                 "traffic": None,                          # PMC counters are collected in separate rocprofv3 passes: see `recorded`

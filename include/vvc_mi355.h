@@ -744,8 +744,11 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  *   CIIP   inter.put_ciip after the PRED of a combined inter / intra coding unit (ff_vvc_predict_ciip, vvc_inter.c:915; luma
  *          coordinates): resid = the inter prediction of the batched stage (w x h pixels of the component, packed rows),
  *          joint = the intra weight ciip_derive_intra_weight (:530-548) gives
- * Neighbour availability is derived on the device from the running list of reconstructed areas exactly as
- * ff_vvc_get_top_available / _left_available do (:574-648), ctb_up / ctb_left flags from the slice and tile tables
+ * Neighbour availability is derived on the device the way ff_vvc_get_top_available / _left_available do (:574-648): the
+ * areas the MARK commands record — for the current CTU only, as in the reference (:508) — are kept as a bitmap of 4x4-luma-sample
+ * units, and the length of the covered run above / left of a block is what the reference's walk over its area list returns for the
+ * areas a decoder produces (disjoint blocks of one partitioning in coding order, inside the CTU, positions and sizes multiples of
+ * four luma samples except the 1- and 2-row intra sub-partitions); ctb_up / ctb_left flags come from the slice and tile tables
  * (ff_vvc_decode_neighbour, vvc_ctu.c:2468), the wide-angle mapping (:693) from the command's mode.
  * Residuals are the outputs of the batched transform stage (vvc355_itx_*_batch with store_coeffs): the inverse transform does
  * not depend on neighbours, so only prediction + add is serialised.  Transform blocks of coding units that are not intra-coded

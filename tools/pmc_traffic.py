@@ -16,10 +16,15 @@ import json
 import sys
 
 STAGES = {                      # stage name of bench.py -> substring of the kernel name
-    "inter_pred_luma_dmvr_bdof": "bipred_kernel",
+    "inter_job_build": "inter_build_kernel",
+    "inter_pred_luma_dmvr_bdof": "bipred_kernel",    # all launches of the kernel in a step: the regular sub-blocks and the CIIP units' inter part
     "inter_pred_chroma": "bipred_chroma_pair_kernel",
-    "intra_pred": "intra_pred_kernel",
+    "inter_pred_gpm": "gpm_kernel",
+    "inter_pred_affine_prof": "affine_kernel",
     "dequant_itx_add_residual": "itx_shape_kernel",
+    "intra_tb_dequant_lfnst_itx": "itx_kernel",        # + lfnst_batch_kernel, listed on its own below
+    "intra_tb_lfnst": "lfnst_batch_kernel",
+    "intra_recon_wavefront": "recon_wavefront_kernel",
     "lmcs_inverse_luma": "lmcs_kernel",
     "deblock_bs": "deblock_bs_kernel",
     "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
@@ -41,8 +46,14 @@ def per_stage(directory, counter, n_passes):
         if pat == "deblock_frame_kernel":
             sel = sel[0::2] if stage == "deblock_vertical" else sel[1::2]
         by_kernel = {}
+        # a kernel launched several times per step with different sizes (bipred_kernel: the regular sub-blocks, then the few CIIP
+        # units) is represented by its largest launch: the one the stage's time and algorithmic bytes refer to
+        largest = {}
         for r in sel:
-            by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            largest[r["Kernel_Name"]] = max(largest.get(r["Kernel_Name"], 0), int(r["Grid_Size"]))
+        for r in sel:
+            if int(r["Grid_Size"]) == largest[r["Kernel_Name"]]:
+                by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
         out[stage] = sum(sum(v) / len(v) for v in by_kernel.values())
     return out
 
