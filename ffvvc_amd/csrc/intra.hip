@@ -1137,8 +1137,8 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 namespace vvc355 {
 
 struct ReconLds {
-    uint16_t arr[2][4][kEdgeLen];     // edge arrays, scratch and CCLM parameters per role (luma wave, chroma wave)
-    int scratch[2][16];
+    uint16_t arr[3][4][kEdgeLen];     // edge arrays and scratch: luma wave, chroma wave (third set: Cr when Cb and Cr are predicted together)
+    int scratch[3][16];
     int prm[2][8];
     uint32_t rmap[2][2][32];          // reconstructed areas of this CTU per channel type as bitmaps of 4x4-luma-sample units: [0] bit b of
                                       // word u = unit (b, u), [1] its transpose (see recon_top_available)
@@ -1488,6 +1488,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             }
         }
         vvc355_recon_cmd c;
+        bool pair_next = false;
         {
             // dword 6 = mode, kind, c_idx, ref_idx: enough to pass over the other wave's commands
             const uint32_t w6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + 6);
@@ -1500,6 +1501,18 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
 #pragma unroll
             for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + i);
             __builtin_memcpy(&c, w, sizeof(c));
+            // Cb and Cr of a coding unit are predicted by two consecutive commands that differ in c_idx only (predict_intra,
+            // vvc_intra.c:263-264): when the next command is that twin, both go through one pass, half a wave each
+            pair_next = false;
+            if (TILE && role == 1 && ((w6 >> 8) & 0xff) == VVC355_RECON_PRED && ((w6 >> 16) & 0xff) == 1 && slot < CHUNK && k + 1 < ctu.n_cmd) {
+                const int ln = slot * CMD_DW;
+                bool same = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 6) == ((w6 & ~0xff0000u) | 0x020000u);
+#pragma unroll
+                for (int i = 2; i < 9; i++)
+                    if (i != 6)
+                        same = same && (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + i) == w[i];
+                pair_next = same;
+            }
         }
         const unsigned long long t_cmd = RPROF_NOW();
         if (c.kind == VVC355_RECON_MARK) {
@@ -1531,6 +1544,21 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             StripRef sr = pick3(c_idx, st0, st1, st2);
             sr.on = TILE && (y & ((ctb >> vs) - 1)) == 0;          // the block sits on the CTU's top edge: the rows above it are the strip
             RPROF_ADD(6 + 32 * role, t_cmd);
+            if constexpr (TILE) {
+                if (pair_next) {
+                    // lanes 0-31: Cb, lanes 32-63: Cr — same job, each half on its own tile, strip, edge arrays and scratch
+                    const int half = tid >> 5;
+                    const LPix plane2{ pl1.p, half ? pl2.base : pl1.base };
+                    StripRef sr2{ st1.p + (half ? (int)(st2.p - st1.p) : 0), st1.pitch, st1.x0s, sr.on };
+                    intra_pred_body<BD, 32>(j, plane2, ps1, L.arr[1 + half], L.scratch[1 + half], tid & 31, sr2, tabs);
+                    group_sync<64>();
+                    k++;                 // the twin is done
+                    slot++;
+                    RPROF_ADD(9 + (int)c.kind + 32 * role, t_cmd);
+                    RPROF_INC(17 + (int)c.kind + 32 * role);
+                    continue;
+                }
+            }
             intra_pred_body<BD, 64>(j, plane, c_idx ? ps1 : ps0, arr, L.scratch[role], tid, sr, tabs);
             if (TILE) group_sync<64>(); else recon_sync_mem();
         } else if (c.kind == VVC355_RECON_CCLM) {
