@@ -466,7 +466,7 @@ __device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int 
     }
     group_sync<NT>();
     for (int t = tid; t < psize * psize; t += NT) {
-        const int y = t / psize, x = t - y * psize;
+        const int y = psize == 8 ? t >> 3 : t >> 2, x = t & (psize - 1);
         int p = 0;
         for (int i = 0; i < in_size; i++)
             p += red[i] * matrix[(y * psize + x) * in_size + i];
@@ -475,14 +475,15 @@ __device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int 
         src.st((up_h - 1 + cx * up_h) + stride * (up_v - 1 + cy * up_v), p);
     }
     group_sync<NT>();
-    for (int t = tid; up_h > 1 && t < psize; t += NT) {            // one lane per row that holds reduced samples
-        const int row = up_v - 1 + t * up_v;
-        int before = left(row);
-        for (int j = 0; j < psize; j++) {
-            const int after = src.ld((j + 1) * up_h - 1 + stride * row);
-            for (int k = 1; k < up_h; k++)
-                src.st(j * up_h + k - 1 + stride * row, ((up_h - k) * before + k * after + up_h / 2) / up_h);
-            before = after;
+    // linear interpolation between the reduced samples (:790-824); the factors are powers of two and the operands non-negative, so
+    // the reference's divisions are shifts.  Horizontal: one lane per output sample of the rows that hold reduced samples.
+    const int lh_ = ilog2i(up_h), lv_ = ilog2i(up_v), lw_ = ilog2i(w);
+    for (int t = tid; up_h > 1 && t < (psize << lw_); t += NT) {
+        const int x = t & (w - 1), row = up_v - 1 + (t >> lw_) * up_v;
+        const int k = (x & (up_h - 1)) + 1, j = x >> lh_;
+        if (k < up_h) {
+            const int before = j ? src.ld(j * up_h - 1 + stride * row) : left(row), after = src.ld((j + 1) * up_h - 1 + stride * row);
+            src.st(x + stride * row, ((up_h - k) * before + k * after + (up_h >> 1)) >> lh_);
         }
     }
     group_sync<NT>();
@@ -491,7 +492,7 @@ __device__ void pred_mip(int tid, PX src, int stride, R top, R left, int w, int 
         for (int j = 0; j < psize; j++) {
             const int after = src.ld(x + stride * ((j + 1) * up_v - 1));
             for (int k = 1; k < up_v; k++)
-                src.st(x + stride * (j * up_v + k - 1), ((up_v - k) * before + k * after + up_v / 2) / up_v);
+                src.st(x + stride * (j * up_v + k - 1), ((up_v - k) * before + k * after + (up_v >> 1)) >> lv_);
             before = after;
         }
     }
