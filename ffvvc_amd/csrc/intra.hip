@@ -1454,65 +1454,81 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
     const int ctb_mask = ctb - 1;
     constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
-    // commands come in chunks of six (60 dwords, lane i holds dword i of the chunk) through the vector-memory path, the next chunk
-    // fetched while this one is walked (its counter is not shared with LDS traffic, so the fetch really overlaps the blocks)
-    constexpr int CHUNK = 6;
-    const uint32_t n_dw = ctu.n_cmd * CMD_DW;
-    uint32_t next_dw = gld<uint32_t>((const uint32_t *)cmds + min((uint32_t)tid, n_dw - 1)), cur_dw = 0;
+    // Each wave walks only its own commands.  Windows of 64 commands: lane i fetches dword 6 (mode, kind, c_idx, ref_idx) of command
+    // win + i, a ballot gives the wave's commands in the window, the next window's dwords are already on their way.  The commands
+    // themselves (ten dwords, lane i holds dword i) are fetched two ahead through the vector-memory path (its counter is not shared
+    // with LDS traffic, so the fetches really overlap the blocks): the next command's contents are at hand when the current one
+    // starts — its residual can be requested early, a Cb / Cr twin recognised.
+    const uint32_t n_cmd = ctu.n_cmd;
     uint16_t (*arr)[kEdgeLen] = L.arr[role];
     const LTabs tabs{ &L.tabs };
-    int slot = CHUNK;
+    auto load_kinds = [&](uint32_t base) -> uint32_t { return gld<uint32_t>((const uint32_t *)(cmds + min(base + (uint32_t)tid, n_cmd - 1)) + 6); };
+    auto own_mask = [&](uint32_t kinds, uint32_t base) -> unsigned long long {
+        return __ballot(base + (uint32_t)tid < n_cmd && ((((kinds >> 16) & 0xff) > 0) == (role == 1)));
+    };
+    auto load_cmd = [&](int idx) -> uint32_t { return idx >= 0 ? gld<uint32_t>((const uint32_t *)(cmds + idx) + min(tid, CMD_DW - 1)) : 0u; };
+    uint32_t win = 0;
+    unsigned long long mask = own_mask(load_kinds(0), 0);
+    uint32_t kinds_nx = load_kinds(64);
+    auto advance = [&]() -> int {         // index of the wave's next command, -1 when its list is exhausted
+        while (!mask) {
+            if (win + 64 >= n_cmd)
+                return -1;
+            win += 64;
+            mask = own_mask(kinds_nx, win);
+            kinds_nx = load_kinds(win + 64);
+        }
+        const int bit = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        return (int)win + bit;
+    };
+    int i0 = advance(), i1 = i0 >= 0 ? advance() : -1, i2 = i1 >= 0 ? advance() : -1;
+    uint32_t d0 = load_cmd(i0), d1 = load_cmd(i1), d2 = load_cmd(i2);
+    // luma_done = every luma command below this index is finished (the chroma wave waits on it before CCLM)
+    if (role == 0)
+        recon_luma_done_set(L, i0 >= 0 ? i0 : (int)n_cmd);
+    auto shift = [&]() {
+        i0 = i1; d0 = d1; i1 = i2; d1 = d2;
+        i2 = i1 >= 0 ? advance() : -1;
+        d2 = load_cmd(i2);
+        if (role == 0)
+            recon_luma_done_set(L, i0 >= 0 ? i0 : (int)n_cmd);          // issued after the finished command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
+    };
     int4 pre[4] = {};                    // residuals fetched one command ahead (the first 1024 of the block)
     int pre_k = -1;
-    for (uint32_t k = 0; k < ctu.n_cmd; k++) {
-        if (slot == CHUNK) {
-            slot = 0;
-            cur_dw = next_dw;
-            next_dw = gld<uint32_t>((const uint32_t *)cmds + min((k + CHUNK) * CMD_DW + (uint32_t)tid, n_dw - 1));
-        }
-        const int lane0 = slot * CMD_DW;
-        slot++;
-        // the next command, when it is in this chunk and a residual block of this wave: start its first loads now, so that they
-        // travel while the current command (usually that block's prediction) runs
-        if (slot < CHUNK && k + 1 < ctu.n_cmd) {
-            const int ln = slot * CMD_DW;
-            const uint32_t n6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 6);
-            if (((n6 >> 8) & 0xff) == VVC355_RECON_RESID && ((((n6 >> 16) & 0xff) > 0) == (role == 1))) {
-                const uint64_t ptr = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 1) << 32);
-                const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 3);
-                const int nn = (int)(wh & 0xffff) * (int)(wh >> 16);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (tid * 4 + 256 * u < nn)
-                        pre[u] = gld<int4>((const int *)ptr + tid * 4 + 256 * u);
-                pre_k = (int)k + 1;
-            }
-        }
+    while (i0 >= 0) {
+        const uint32_t k = (uint32_t)i0;
         vvc355_recon_cmd c;
         bool pair_next = false;
         {
-            // dword 6 = mode, kind, c_idx, ref_idx: enough to pass over the other wave's commands
-            const uint32_t w6 = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + 6);
-            if ((((w6 >> 16) & 0xff) > 0) != (role == 1)) {
-                if (role == 0)
-                    recon_luma_done_set(L, (int)k + 1);
-                continue;
-            }
             uint32_t w[CMD_DW];
 #pragma unroll
-            for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, lane0 + i);
+            for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)d0, i);
             __builtin_memcpy(&c, w, sizeof(c));
-            // Cb and Cr of a coding unit are predicted by two consecutive commands that differ in c_idx only (predict_intra,
-            // vvc_intra.c:263-264): when the next command is that twin, both go through one pass, half a wave each
-            pair_next = false;
-            if (TILE && role == 1 && ((w6 >> 8) & 0xff) == VVC355_RECON_PRED && ((w6 >> 16) & 0xff) == 1 && slot < CHUNK && k + 1 < ctu.n_cmd) {
-                const int ln = slot * CMD_DW;
-                bool same = (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + 6) == ((w6 & ~0xff0000u) | 0x020000u);
+            if (i1 >= 0) {
+                const uint32_t n6 = (uint32_t)__builtin_amdgcn_readlane((int)d1, 6);
+                // the wave's next command is a residual block: start its first loads now, so that they travel while this command
+                // (usually that block's prediction) runs — unless this command is about to use the registers they go to
+                if (((n6 >> 8) & 0xff) == VVC355_RECON_RESID && pre_k != i0) {
+                    const uint64_t ptr = (uint32_t)__builtin_amdgcn_readlane((int)d1, 0) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)d1, 1) << 32);
+                    const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)d1, 3);
+                    const int nn = (int)(wh & 0xffff) * (int)(wh >> 16);
 #pragma unroll
-                for (int i = 2; i < 9; i++)
-                    if (i != 6)
-                        same = same && (uint32_t)__builtin_amdgcn_readlane((int)cur_dw, ln + i) == w[i];
-                pair_next = same;
+                    for (int u = 0; u < 4; u++)
+                        if (tid * 4 + 256 * u < nn)
+                            pre[u] = gld<int4>((const int *)ptr + tid * 4 + 256 * u);
+                    pre_k = i1;
+                }
+                // Cb and Cr of a coding unit are predicted by two consecutive commands that differ in c_idx only (predict_intra,
+                // vvc_intra.c:263-264): when the next command is that twin, both go through one pass, half a wave each
+                if (TILE && c.kind == VVC355_RECON_PRED && c.c_idx == 1 && i1 == i0 + 1) {
+                    bool same = n6 == ((w[6] & ~0xff0000u) | 0x020000u);
+#pragma unroll
+                    for (int i = 2; i < 9; i++)
+                        if (i != 6)
+                            same = same && (uint32_t)__builtin_amdgcn_readlane((int)d1, i) == w[i];
+                    pair_next = same;
+                }
             }
         }
         const unsigned long long t_cmd = RPROF_NOW();
@@ -1553,10 +1569,10 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                     StripRef sr2{ st1.p + (half ? (int)(st2.p - st1.p) : 0), st1.pitch, st1.x0s, sr.on };
                     intra_pred_body<BD, 32>(j, plane2, ps1, L.arr[1 + half], L.scratch[1 + half], tid & 31, sr2, tabs);
                     group_sync<64>();
-                    k++;                 // the twin is done
-                    slot++;
                     RPROF_ADD(9 + (int)c.kind + 32 * role, t_cmd);
                     RPROF_INC(17 + (int)c.kind + 32 * role);
+                    shift();             // the twin is done as well
+                    shift();
                     continue;
                 }
             }
@@ -1625,10 +1641,9 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                 add4(i, gld<int4>(res + i));
             if (TILE) group_sync<64>(); else recon_sync_mem();
         }
-        if (role == 0)
-            recon_luma_done_set(L, (int)k + 1);          // issued after the command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
         RPROF_ADD(9 + (int)c.kind + 32 * role, t_cmd);
         RPROF_INC(17 + (int)c.kind + 32 * role);
+        shift();
     }
     RPROF_ADD(3 + 32 * role, t_loop);
 #ifdef VVC355_RECON_PROF
