@@ -97,6 +97,10 @@ RUNTIME_SIGNATURES = {
     "graph_launch":   ("v", "pp"),
     "graph_destroy":  ("v", "p"),
     "version":        ("p", ""),
+    "set_error_policy": ("v", "i"),
+    "last_error":     ("i", ""),
+    "last_error_string": ("p", ""),
+    "clear_error":    ("v", ""),
 }
 
 BATCH_SIGNATURES = {

@@ -8,15 +8,16 @@
 
 #define VVC355_PB 128   // MAX_PB_SIZE: implicit row stride of int16 MC intermediates (libavcodec/vvc/vvc_ctu.h:48)
 
-// DSP slots return void and cannot report failure (vvcdsp.h:48-158): a HIP error is fatal and loud.
+// DSP slots return void and cannot report failure (vvcdsp.h:48-158): by default a HIP error is fatal and loud.  A host that drives the
+// batched / frame entries itself can ask for errors to be recorded instead (vvc355_set_error_policy(1)): the first failure is kept
+// (vvc355_last_error / _string), the entry goes on (HIP errors are sticky, later calls fail too) and the host checks after the
+// stage or at its stream synchronisation.
+namespace vvc355 { void hip_fail(const char *expr, int err, const char *what, const char *file, int line); }
 #define HIP_CHECK(expr)                                                                         \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess) {                                                                 \
-            fprintf(stderr, "vvc_mi355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
-                    __FILE__, __LINE__);                                                        \
-            abort();                                                                            \
-        }                                                                                       \
+        if (e_ != hipSuccess)                                                                   \
+            ::vvc355::hip_fail(#expr, (int)e_, hipGetErrorString(e_), __FILE__, __LINE__);      \
     } while (0)
 
 namespace vvc355 {

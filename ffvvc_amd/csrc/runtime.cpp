@@ -8,6 +8,23 @@ static constexpr size_t kArenaBytes = 48u << 20;   // far above any single slot 
 // the slots from its own worker threads (libavutil/executor.c:92-110, vvc_thread.c:647-654), which never called hipSetDevice.
 std::atomic<int> g_device{ 0 };
 
+// error policy of HIP_CHECK: 0 = print and abort (default: the void slots have no other channel), 1 = print, record the first failure
+// and go on (for hosts that call the batched / frame entries and check vvc355_last_error())
+std::atomic<int> g_error_policy{ 0 }, g_last_error{ 0 };
+static char g_last_error_text[256];
+
+const char *last_error_text() { return g_last_error_text; }
+
+void hip_fail(const char *expr, int err, const char *what, const char *file, int line)
+{
+    fprintf(stderr, "vvc_mi355: %s failed: %s (%s:%d)\n", expr, what, file, line);
+    if (g_error_policy.load() == 0)
+        abort();
+    int none = 0;
+    if (g_last_error.compare_exchange_strong(none, err))
+        snprintf(g_last_error_text, sizeof(g_last_error_text), "%s failed: %s (%s:%d)", expr, what, file, line);
+}
+
 ThreadCtx::ThreadCtx()
 {
     device = g_device.load();

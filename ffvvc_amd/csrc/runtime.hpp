@@ -21,6 +21,8 @@ struct ThreadCtx {
 };
 ThreadCtx &thread_ctx();
 extern std::atomic<int> g_device;
+extern std::atomic<int> g_error_policy, g_last_error;
+const char *last_error_text();
 
 // A staged host rectangle: `dev` is the device address that corresponds to the caller's host pointer.
 struct Staged {

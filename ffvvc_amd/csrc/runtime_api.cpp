@@ -11,6 +11,11 @@ int vvc355_device_count(void)
         return 0;
     return n;
 }
+void vvc355_set_error_policy(int record_instead_of_abort) { vvc355::g_error_policy.store(record_instead_of_abort ? 1 : 0); }
+int vvc355_last_error(void) { return vvc355::g_last_error.load(); }
+const char *vvc355_last_error_string(void) { return vvc355::g_last_error.load() ? vvc355::last_error_text() : ""; }
+void vvc355_clear_error(void) { (void)hipGetLastError(); vvc355::g_last_error.store(0); }
+
 void vvc355_set_device(int ordinal)
 {
     HIP_CHECK(hipSetDevice(ordinal));

@@ -32,6 +32,13 @@ extern "C" {
 /* ------------------------------------------------------------------ runtime helpers (runtime_api.cpp) */
 /* Device count / selection and plain device memory, for C hosts that keep frames resident in HBM. */
 int   vvc355_device_count(void);
+/* Error policy of the batched / frame entries (the void slots have no error channel: vvcdsp.h).  Default 0: a HIP failure prints
+ * and aborts.  With 1 the first failure is recorded instead — the entry goes on, later HIP calls fail too — and the host checks
+ * vvc355_last_error() (a hipError_t value, 0 = none) after a stage or at its stream synchronisation. */
+void  vvc355_set_error_policy(int record_instead_of_abort);
+int   vvc355_last_error(void);
+const char *vvc355_last_error_string(void);
+void  vvc355_clear_error(void);
 void  vvc355_set_device(int ordinal);           /* process-wide: also the device of every thread that calls a slot afterwards */
 void *vvc355_malloc(size_t bytes);
 void  vvc355_free(void *dev);

@@ -246,3 +246,21 @@ def test_slots_called_from_four_threads_at_once(dev, orc):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_error_policy_records_instead_of_aborting(dev):
+    """vvc355_set_error_policy(1): a failing HIP call inside an entry is recorded, not fatal (freeing an address that is no
+    allocation: rejected by the runtime without touching the device); the default policy is restored afterwards."""
+    import ctypes
+    dev.vvc355_clear_error()
+    assert dev.vvc355_last_error() == 0
+    dev.vvc355_set_error_policy(1)
+    try:
+        dev.vvc355_free(ctypes.c_void_p(0x1234560))
+        assert dev.vvc355_last_error() != 0
+        assert b"failed" in ctypes.string_at(dev.vvc355_last_error_string())
+        dev.vvc355_clear_error()
+        assert dev.vvc355_last_error() == 0
+    finally:
+        dev.vvc355_set_error_policy(0)
