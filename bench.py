@@ -1393,6 +1393,11 @@ def main(argv=None):
     args = parse_args(argv)
     if args.cpu_worker is not None:
         return cpu_worker_main(args)
+    # One HIP stream per frame in flight only helps if the streams do not share hardware queues: the runtime's default of 4 maps
+    # several streams onto one in-order queue, and a frame's 2 ms intra pass then holds up the other frame behind it (measured, 8
+    # frames in flight: 502 / 660 / 685 / 808 frames/s with 2 / 4 / 8 / 16 queues).  Set before the HIP runtime initialises; a
+    # value already in the environment wins.  A host that uses the C ABI with several streams needs the same setting.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 2 * max(1, args.frames_in_flight))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
     global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES
@@ -1560,7 +1565,8 @@ def main(argv=None):
                             f"{'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
                 "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
-                "parallelism": f"{world} independent frame stream(s), one per GPU, no collective; {n_ff} frame(s) in flight per GPU",
+                "parallelism": f"{world} independent frame stream(s), one per GPU, no collective; {n_ff} frame(s) in flight per GPU, one HIP stream each, "
+                               f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
             },
             "roofline": {
                 "stage": dom.name,

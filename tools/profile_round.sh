@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_r02
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=16     # what bench.py sets for itself; exported here because the profiler starts the runtime first
 B="python3 $R/bench.py --no-cpu-baseline --no-verify"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o run -- $B --steps 20 --warmup 3 > $O/trace_default.log 2>&1
 echo trace_default done
