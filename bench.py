@@ -1572,16 +1572,18 @@ def main(argv=None):
                 "stage": dom.name,
                 "kernel": dom.kernel,
                 "bound": "hbm",
-                "achieved": achieved,
+                # HIP events on the launch stream around the stage, one frame alone (the K-step pass right before the timed region):
+                # the kernels' own duration, which is what rocprofv3's per-kernel average of `--frames-in-flight 1` shows
+                # (profiles/r02_bench_f1_kernel_stats.csv).  Inside the timed region the other frames in flight share the device and an
+                # event pair also spans the time the stage's kernels wait for CUs: `in_timed_region`.
+                "achieved": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "ms_per_launch": stage_ms[dom.name],
+                "frac": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_launch": breakdown[dom.name],
                 "algorithmic_bytes_per_launch": dom.algorithmic_bytes,
-                # the same stage of one frame running alone (the untimed single-frame pass): what the kernel reaches without the
-                # other frames in flight sharing the device
-                "isolated": {"ms_per_launch": breakdown[dom.name], "achieved": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9,
-                             "frac": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "in_timed_region": {"ms_per_launch": stage_ms[dom.name], "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                    "frames_in_flight": n_ff},
                 "note": ("dominant = the batched stage with the largest launch time; the in-order intra pass (intra_recon_wavefront) is a latency-bound "
                          "dependent chain on a few hundred waves that overlaps the other frames in flight — see stages / frame_latency_ms") if n_ff > 1 else "",
                 "traffic": None,                          # PMC counters are collected in separate rocprofv3 passes: see `recorded`
