@@ -319,7 +319,7 @@ class InterSlice(ctypes.Structure):
 class InterFrame(ctypes.Structure):
     """Mirror of vvc355_inter_frame."""
     _fields_ = [("dst", ctypes.c_uint64 * 3), ("mvf", ctypes.c_uint64), ("refs", ctypes.c_uint64), ("pus", ctypes.c_uint64), ("slices", ctypes.c_uint64),
-                ("jobs_luma", ctypes.c_uint64), ("jobs_chroma", ctypes.c_uint64), ("records", ctypes.c_uint64),
+                ("jobs_luma", ctypes.c_uint64), ("jobs_chroma", ctypes.c_uint64), ("records", ctypes.c_uint64), ("dmvr_mvf", ctypes.c_uint64),
                 ("dst_stride", ctypes.c_int32 * 3), ("mvf_stride", ctypes.c_int32), ("n_pus", ctypes.c_int32), ("n_jobs", ctypes.c_int32),
                 ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("chroma_format_idc", ctypes.c_uint8), ("pixel_shift", ctypes.c_uint8),

@@ -85,6 +85,27 @@ __global__ __launch_bounds__(256) void inter_build_kernel(const vvc355_inter_fra
         }
 }
 
+// set_dmvr_info (vvc_inter.c:750-762) after the luma launch: one lane per luma job; a DMVR sub-block's 4x4 units get its MvField with
+// the refined motion of its record
+__global__ __launch_bounds__(256) void inter_dmvr_info_kernel(const vvc355_inter_frame *__restrict__ fp)
+{
+    const vvc355_inter_frame f = load_uniform(fp);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n_jobs)
+        return;
+    const vvc355_bipred_job *j = (const vvc355_bipred_job *)f.jobs_luma + i;
+    if (!j->dmvr)
+        return;
+    const vvc355_bipred_result *r = (const vvc355_bipred_result *)f.records + i;
+    const MvFieldDev *src = (const MvFieldDev *)f.mvf;
+    MvFieldDev *dst = (MvFieldDev *)f.dmvr_mvf;
+    MvFieldDev m = src[(j->y >> 2) * f.mvf_stride + (j->x >> 2)];
+    m.mv[0][0] = r->mv[0]; m.mv[0][1] = r->mv[1]; m.mv[1][0] = r->mv[2]; m.mv[1][1] = r->mv[3];
+    for (int y = j->y; y < j->y + j->h; y += 4)
+        for (int x = j->x; x < j->x + j->w; x += 4)
+            dst[(y >> 2) * f.mvf_stride + (x >> 2)] = m;
+}
+
 } // namespace vvc355
 
 extern "C" {
@@ -101,6 +122,10 @@ void vvc355_inter_frame_pass(void *stream, int bd, const vvc355_inter_frame *fra
     if (frame_host->n_pus <= 0 || frame_host->n_jobs <= 0) return;
     vvc355_inter_frame_build(stream, frame_dev, frame_host);
     vvc355_bipred_batch(stream, bd, (const vvc355_bipred_job *)frame_host->jobs_luma, frame_host->n_jobs);
+    if (frame_host->dmvr_mvf) {
+        hipLaunchKernelGGL(vvc355::inter_dmvr_info_kernel, dim3((frame_host->n_jobs + 255) / 256), dim3(256), 0, (hipStream_t)stream, frame_dev);
+        HIP_CHECK(hipGetLastError());
+    }
     if (frame_host->chroma_format_idc)
         vvc355_bipred_chroma_batch(stream, bd, (const vvc355_bipred_job *)frame_host->jobs_chroma, 2 * frame_host->n_jobs);
 }

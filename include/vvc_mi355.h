@@ -518,6 +518,9 @@ typedef struct vvc355_inter_frame {
     uint64_t dst[3];              /* the current picture's planes */
     uint64_t mvf, refs, pus, slices;
     uint64_t jobs_luma, jobs_chroma, records;
+    uint64_t dmvr_mvf;            /* 0, or DEVICE MvField[] with mvf's geometry: fc->ref->tab_dmvr_mvf.  The pass then does set_dmvr_info
+                                   * (vvc_inter.c:750-762): every 4x4 unit of a DMVR sub-block gets the sub-block's MvField with the
+                                   * refined motion.  (Units of other blocks are filled by the parser, vvc_ctu.c:1699.) */
     int32_t  dst_stride[3];       /* bytes */
     int32_t  mvf_stride;          /* MvField entries per row (min_pu_width) */
     int32_t  n_pus, n_jobs;

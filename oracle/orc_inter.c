@@ -688,6 +688,22 @@ ORC_API void orc_inter_frame_pass(int bd, const orc_inter_frame *f)
     const orc_bipred_job *jl = (const orc_bipred_job *)(uintptr_t)f->jobs_luma, *jc = (const orc_bipred_job *)(uintptr_t)f->jobs_chroma;
     for (int i = 0; i < f->n_jobs; i++)
         orc_bipred_block(bd, jl + i);
+    if (f->dmvr_mvf) {
+        /* set_dmvr_info (vvc_inter.c:750-762) */
+        const orc_mv_field *src = (const orc_mv_field *)(uintptr_t)f->mvf;
+        orc_mv_field *dst = (orc_mv_field *)(uintptr_t)f->dmvr_mvf;
+        const orc_bipred_result *rec = (const orc_bipred_result *)(uintptr_t)f->records;
+        for (int i = 0; i < f->n_jobs; i++) {
+            const orc_bipred_job *j = jl + i;
+            if (!j->dmvr)
+                continue;
+            orc_mv_field m = src[(j->y >> 2) * f->mvf_stride + (j->x >> 2)];
+            m.mv[0][0] = rec[i].mv[0]; m.mv[0][1] = rec[i].mv[1]; m.mv[1][0] = rec[i].mv[2]; m.mv[1][1] = rec[i].mv[3];
+            for (int y = j->y; y < j->y + j->h; y += 4)
+                for (int x = j->x; x < j->x + j->w; x += 4)
+                    dst[(y >> 2) * f->mvf_stride + (x >> 2)] = m;
+        }
+    }
     if (f->chroma_format_idc)
         for (int i = 0; i < 2 * f->n_jobs; i++)
             orc_bipred_block(bd, jc + i);

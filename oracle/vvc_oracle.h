@@ -140,6 +140,7 @@ typedef struct orc_inter_frame {
     uint64_t dst[3];
     uint64_t mvf, refs, pus, slices;
     uint64_t jobs_luma, jobs_chroma, records;
+    uint64_t dmvr_mvf;
     int32_t  dst_stride[3];
     int32_t  mvf_stride;
     int32_t  n_pus, n_jobs;

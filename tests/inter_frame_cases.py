@@ -85,12 +85,13 @@ class InterWork:
                     s1.weight[l][c][r] = int(rng.integers(-32, 96))
                     s1.offset[l][c][r] = int(rng.integers(-20, 21))
 
-    def frame(self, dst_ptrs, dst_strides, mvf_ptr, refs_ptr, pus_ptr, slices_ptr, jl_ptr, jc_ptr, rec_ptr, hs, vs, isz):
+    def frame(self, dst_ptrs, dst_strides, mvf_ptr, refs_ptr, pus_ptr, slices_ptr, jl_ptr, jc_ptr, rec_ptr, hs, vs, isz, dmvr_ptr=0):
         f = abi.InterFrame()
         for c in range(3):
             f.dst[c], f.dst_stride[c] = dst_ptrs[c], dst_strides[c]
         f.mvf, f.refs, f.pus, f.slices = mvf_ptr, refs_ptr, pus_ptr, slices_ptr
         f.jobs_luma, f.jobs_chroma, f.records = jl_ptr, jc_ptr, rec_ptr
+        f.dmvr_mvf = dmvr_ptr
         f.mvf_stride, f.n_pus, f.n_jobs = self.width // 4, len(self.pus), self.n_jobs
         f.width, f.height = self.width, self.height
         f.hs, f.vs, f.chroma_format_idc, f.pixel_shift = hs, vs, 1, int(isz == 2)

@@ -46,5 +46,5 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.MvField) == 24 and ctypes.sizeof(abi.BsFrame) == 312
     assert ctypes.sizeof(abi.ReconCmd) == 40 and ctypes.sizeof(abi.ReconCtu) == 8 and ctypes.sizeof(abi.ReconFrame) == 120
     assert ctypes.sizeof(abi.LfnstJob) == 32 and ctypes.sizeof(abi.GpmJob) == 112 and ctypes.sizeof(abi.ItxJob) == 48
-    assert ctypes.sizeof(abi.InterPu) == 20 and ctypes.sizeof(abi.InterSlice) == 388 and ctypes.sizeof(abi.InterFrame) == 120 and ctypes.sizeof(abi.RefPic) == 40
+    assert ctypes.sizeof(abi.InterPu) == 20 and ctypes.sizeof(abi.InterSlice) == 388 and ctypes.sizeof(abi.InterFrame) == 128 and ctypes.sizeof(abi.RefPic) == 40
     assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136

@@ -41,10 +41,11 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h):
     want = [np.zeros((ph, pw), base[0].dtype) for (pw, ph) in dims]
     h_jl, h_jc = np.zeros(work.n_jobs, jl_dt), np.zeros(2 * work.n_jobs, jl_dt)
     h_rec = np.zeros((work.n_jobs, 8), np.int32)
+    h_dmvr = work.mvf.copy()                      # tab_dmvr_mvf as the parser leaves it: a copy of the motion field
     h_refs = ref_table([[[refs[l][r][c].ctypes.data for c in range(3)] for r in range(2)] for l in range(2)],
                        [[[refs[l][r][c].shape[1] * isz for c in range(3)] for r in range(2)] for l in range(2)])
     hf = work.frame([p.ctypes.data for p in want], [d[0] * isz for d in dims], work.mvf.ctypes.data, ctypes.addressof(h_refs), work.pus.ctypes.data,
-                    ctypes.addressof(work.slices), h_jl.ctypes.data, h_jc.ctypes.data, h_rec.ctypes.data, hs, vs, isz)
+                    ctypes.addressof(work.slices), h_jl.ctypes.data, h_jc.ctypes.data, h_rec.ctypes.data, hs, vs, isz, dmvr_ptr=h_dmvr.ctypes.data)
     orc.orc_inter_frame_pass(bd, ctypes.byref(hf))
 
     # ---- device
@@ -57,7 +58,8 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h):
     d_mvf, d_pus = batch.DeviceBuffer.from_host(work.mvf.view(np.uint8)), batch.DeviceBuffer.from_host(work.pus.view(np.uint8))
     d_sl = batch.DeviceBuffer.from_host(np.frombuffer(bytes(work.slices), np.uint8))
     d_jl, d_jc, d_rec = batch.DeviceBuffer(h_jl.nbytes), batch.DeviceBuffer(h_jc.nbytes), batch.DeviceBuffer(h_rec.nbytes)
-    df = work.frame([b.ptr for b in d_dst], pitches, d_mvf.ptr, d_reft.ptr, d_pus.ptr, d_sl.ptr, d_jl.ptr, d_jc.ptr, d_rec.ptr, hs, vs, isz)
+    d_dmvr = batch.DeviceBuffer.from_host(work.mvf.view(np.uint8))
+    df = work.frame([b.ptr for b in d_dst], pitches, d_mvf.ptr, d_reft.ptr, d_pus.ptr, d_sl.ptr, d_jl.ptr, d_jc.ptr, d_rec.ptr, hs, vs, isz, dmvr_ptr=d_dmvr.ptr)
     d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
     dev.vvc355_inter_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df))
     dev.vvc355_stream_sync(None)
@@ -91,3 +93,6 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h):
         bad = np.argwhere(got != want[c])
         assert len(bad) == 0, f"component {c}: {len(bad)} samples differ, first at (y, x) = {bad[0].tolist()}"
     assert np.array_equal(d_rec.to_host(np.int32, h_rec.shape)[:, :7], h_rec[:, :7])
+    # set_dmvr_info: the refined motion field
+    g_dmvr = d_dmvr.to_host(np.uint8, (work.mvf.nbytes,)).view(ifc.MVF_DT).reshape(work.mvf.shape)
+    assert np.array_equal(g_dmvr, h_dmvr) and not np.array_equal(h_dmvr, work.mvf)
