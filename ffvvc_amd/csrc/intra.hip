@@ -999,6 +999,51 @@ __device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX c
     }
     group_sync<NT>();
     const int lw = ilog2(w);                    // block sides are powers of two
+    if (hs == 1 && vs == 1 && w >= 4) {
+        // 4:2:0: four chroma samples of a row per lane.  Their down-sampling windows (cclm_ds_luma) cover luma columns -1 .. 7 of the
+        // row pair: one single load and two four-sample loads per luma row instead of five or six loads per chroma sample.
+        const int lq = lw - 2;
+        const int a0 = prm[0], a1 = prm[1], b0 = prm[2], b1 = prm[3], k0 = prm[4], k1 = prm[5];
+        for (int q = tid; q < (h << lq); q += NT) {
+            const int yy = q >> lq, xx0 = (q & ((1 << lq) - 1)) << 2;
+            const int o = (j.y0 + 2 * yy) * ls + j.x0 + 2 * xx0;       // luma sample (2 xx0, 2 yy) of the block
+            int r0[9], r1[9], v[4];                                    // columns -1 .. 7
+            luma.ld4(o, r0 + 1); luma.ld4(o + 4, r0 + 5);
+            luma.ld4(o + ls, r1 + 1); luma.ld4(o + ls + 4, r1 + 5);
+            const bool has_left = xx0 || avail_l;
+            r0[0] = has_left ? luma.ld(o - 1) : r0[1];
+            if (j.collocated) {
+                const int ty = (yy || avail_t) ? -1 : 0;
+                int up[8];
+                if (ty == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) up[e] = r0[1 + e];
+                } else if (sl.on && !yy) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) up[2 * e] = sl.at(j.x0 + 2 * xx0 + 2 * e, -1);
+                } else {
+                    luma.ld4(o - ls, up); luma.ld4(o - ls + 4, up + 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    v[e] = (r0[2 * e] + up[2 * e] + 4 * r0[2 * e + 1] + r0[2 * e + 2] + r1[2 * e + 1] + 4) >> 3;
+            } else {
+                r1[0] = has_left ? luma.ld(o + ls - 1) : r1[1];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    v[e] = (r0[2 * e] + r1[2 * e] + 2 * (r0[2 * e + 1] + r1[2 * e + 1]) + r0[2 * e + 2] + r1[2 * e + 2] + 4) >> 3;
+            }
+            int u[4], t[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                u[e] = clip_px<BD>(((v[e] * a0) >> k0) + b0);
+                t[e] = clip_px<BD>(((v[e] * a1) >> k1) + b1);
+            }
+            cb.st4((y + yy) * cs0 + x + xx0, u[0], u[1], u[2], u[3]);
+            cr.st4((y + yy) * cs1 + x + xx0, t[0], t[1], t[2], t[3]);
+        }
+        return;
+    }
     for (int i = tid; i < w * h; i += NT) {
         const int yy = i >> lw, xx = i & (w - 1);
         const int dsy = cclm_ds_luma<BD>(j, luma, ls, xx, yy, sl);
@@ -1539,7 +1584,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             const int span = t ? uw : uh, first = t ? ux : uy, len = t ? uh : uw, at = t ? uy : ux;
             if (i < span)
                 L.rmap[role][t][first + i] |= (len >= 32 ? ~0u : ((1u << len) - 1)) << at;
-            group_sync<64>();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // LDS accesses of a wave stay in order; this only pins the compiler
         } else if (c.kind == VVC355_RECON_PRED) {
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
             const int x = c.x0 >> hs, y = c.y0 >> vs, w = c.w >> hs, h = c.h >> vs;
