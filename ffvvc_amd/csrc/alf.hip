@@ -635,14 +635,17 @@ extern "C" {
 // ---- batched (device-resident) entries
 void vvc355_alf_luma_batch(void *stream, int bd, int fused, const vvc355_alf_job *jobs_dev, int n_jobs)
 {
+    if (n_jobs <= 0) return;
     launch_luma(bd, fused ? 1 : 0, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 void vvc355_alf_chroma_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, int n_jobs)
 {
+    if (n_jobs <= 0) return;
     launch_chroma(bd, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 void vvc355_alf_cc_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, int n_jobs)
 {
+    if (n_jobs <= 0) return;
     launch_cc(bd, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 

@@ -436,11 +436,13 @@ extern "C" {
 
 void vvc355_mc_batch(void *stream, int bd, const vvc355_mc_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
+    if (n_jobs <= 0) return;
     launch_mc(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
 }
 
 void vvc355_blend_batch(void *stream, int bd, const vvc355_blend_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
+    if (n_jobs <= 0) return;
     launch_blend(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
 }
 

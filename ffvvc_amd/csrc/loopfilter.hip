@@ -1159,6 +1159,7 @@ extern "C" {
 
 void vvc355_sao_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_w, int max_h)
 {
+    if (n_jobs <= 0) return;
     launch_sao(bd, jobs_dev, n_jobs, max_w, max_h, (hipStream_t)stream);
 }
 
@@ -1198,6 +1199,7 @@ void vvc355_sao_frame_pass(void *stream, int bd, const vvc355_sao_frame *frame_d
 
 void vvc355_sao_ctb_batch(void *stream, int bd, const vvc355_sao_job *jobs_dev, int n_jobs, int max_h)
 {
+    if (n_jobs <= 0) return;
     launch_sao_vec(bd, jobs_dev, n_jobs, max_h, (hipStream_t)stream);
 }
 
@@ -1228,6 +1230,7 @@ void vvc355_deblock_frame_pass(void *stream, int bd, const vvc355_deblock_frame 
 
 void vvc355_deblock_batch(void *stream, int bd, const vvc355_deblock_job *jobs_dev, int n_jobs)
 {
+    if (n_jobs <= 0) return;
     launch_deblock(bd, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 
