@@ -1476,20 +1476,26 @@ def main(argv=None):
     barrier()
     events = {}
     if args.graph:
-        # the timed region replays one captured hipGraph per step (one launch per frame instead of ~25); no events inside it
-        gs = lib.vvc355_stream_create()
-        lib.vvc355_graph_begin(gs)
-        for st in chain:
-            st.launch(gs)
-        gexec = lib.vvc355_graph_end(gs)
-        lib.vvc355_graph_launch(gexec, gs)
-        lib.vvc355_stream_sync(gs)
+        # the timed region replays one captured hipGraph per frame in flight and step (one launch per frame instead of ~30), each on a
+        # stream of its own; no events inside it
+        gstreams = [lib.vvc355_stream_create() for _ in range(n_ff)]
+        gexecs = []
+        for f in range(n_ff):
+            lib.vvc355_graph_begin(gstreams[f])
+            for st in chains[f]:
+                st.launch(gstreams[f])
+            gexecs.append(lib.vvc355_graph_end(gstreams[f]))
+        for f in range(n_ff):
+            lib.vvc355_graph_launch(gexecs[f], gstreams[f])
+        for f in range(n_ff):
+            lib.vvc355_stream_sync(gstreams[f])
         barrier()
-        n_ff = 1
         t0 = time.perf_counter()
         for k in range(args.steps):
-            lib.vvc355_graph_launch(gexec, gs)
-        lib.vvc355_stream_sync(gs)
+            for f in range(n_ff):
+                lib.vvc355_graph_launch(gexecs[f], gstreams[f])
+        for f in range(n_ff):
+            lib.vvc355_stream_sync(gstreams[f])
         elapsed = time.perf_counter() - t0
     else:
         t0 = time.perf_counter()
