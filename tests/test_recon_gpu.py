@@ -77,3 +77,12 @@ def test_recon_mixed_picture(dev, orc, bd):
     assert 0 < len(work.order) <= 12 * 7 and (work.cmds["kind"] == abi.RECON_CIIP).sum() > 20
     work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_ctu=intra_ctu)
     assert 0 < len(work.order) < 12 * 7
+
+
+def test_recon_more_ctus_than_workgroups(dev, orc):
+    """4:2:0 with 32x32 CTUs on a picture of 576 CTUs: the LDS-tile path with the smallest CTU size, and more CTUs than the pass has
+    persistent workgroups (256), so every workgroup walks several CTUs and waits on flags raised by workgroups that took later and
+    earlier tickets."""
+    rng = np.random.default_rng(0x5EED0E99)
+    work, changed = run_case(dev, orc, rng, 10, 1024, 576, 5, (1, 1), intra_frac=1.0, n_slices=2)
+    assert len(work.order) == 32 * 18 and changed > 1024 * 576 // 2
