@@ -273,6 +273,9 @@ def build_chain(lib, torch, fr):
         got_l, got_c = env.after[ptr(d_bl)].view(luma_jobs.dtype), env.after[ptr(d_bc)].view(chroma_jobs.dtype)
         return n_bl + n_bc, int((got_l != luma_jobs).sum() + (got_c != chroma_jobs).sum())
 
+    # filled once here as well, so that a profiling run with --only on the prediction stages alone finds valid jobs
+    lib.vvc355_inter_frame_build(None, ptr(d_inf), ctypes.addressof(inf))
+    lib.vvc355_stream_sync(None)
     chain.append(Stage("inter_job_build", "inter_build_kernel", lambda st: lib.vvc355_inter_frame_build(st, ptr(d_inf), ctypes.addressof(inf)),
                        n_blk * 3 * ctypes.sizeof(abi.BipredJob), writes=[d_bl, d_bc], check=check_build))
     inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)
