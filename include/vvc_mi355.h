@@ -739,7 +739,7 @@ int  vvc355_ilfnst_transform(int *coeffs, int w, int h, int pred_mode_intra, int
 /* returns trh | trv << 4; the batched transform entries apply the same rule on the device when a job sets VVC355_ITX_DERIVE_TYPE */
 int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int c_idx, int w, int h);
 
-/* ------------------------------------------------------------------ RECON stage driver: in-order CTU interpreter + wavefront (recon.hip) */
+/* ------------------------------------------------------------------ RECON stage driver: in-order CTU interpreter + wavefront (intra.hip) */
 
 /*
  * ff_vvc_reconstruct (vvc_intra.c:498-527) for a whole picture: every CTU's coding units are walked in decoding order — intra
