@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 from ffvvc_amd import abi, batch, sharding  # noqa: E402
 
+INTER_FRAC = 0.8               # fraction of inter CTUs (--inter-frac; 0 = an all-intra picture: BASELINE.json configs[1])
 ALF_TABLES = True              # ALF through the stage driver (job descriptors built on the device from ALFParams / APS tables); --alf-jobs: host-built jobs
 SAO_TABLES = True              # SAO through the stage driver (parameters derived on the device from per-CTB tables); --sao-jobs: host-built jobs
 DEBLOCK_JOBS = False           # deblocking through the stage driver (edge parameters derived from side tables); --deblock-jobs: host-built jobs
@@ -178,8 +179,8 @@ def build_chain(lib, torch, fr):
     rec_ptrs = [ptr(t) for t in rec]
 
     # CTU kinds: 80 % inter, 20 % intra; of the inter CTUs a few are affine and a few combined inter / intra (CIIP)
-    ctu_inter = rng.random(fr.n_ctus) < 0.8
-    ctu_ciip = ctu_inter & (rng.random(fr.n_ctus) < CIIP_FRAC / 0.8)
+    ctu_inter = rng.random(fr.n_ctus) < INTER_FRAC
+    ctu_ciip = ctu_inter & (rng.random(fr.n_ctus) < CIIP_FRAC / max(INTER_FRAC, 1e-9))
 
     # ---------------------------------------------------------------- inter prediction: regular bi-predicted 16x16 luma sub-blocks
     # with DMVR and BDOF switched on (search, parametric refinement, 8-tap MC at the refined motion, BDOF), then their 8x8
@@ -504,6 +505,8 @@ def build_chain(lib, torch, fr):
             kc = (y0 // cs) * fr.ncx + (x0 // cs)
             keep = ctu_inter[kc] & ~ctu_ciip[kc]       # the intra CTUs have their own transform blocks (below); the CIIP coding units carry no residual here
             x0, y0 = x0[keep], y0[keep]
+            if not len(x0):
+                continue
             j = batch.job_array(abi.ItxJob, len(x0))
             lg = int(np.log2(n))
             j["coeffs"] = coeff_off + np.arange(len(x0), dtype=np.int64) * (n * n * 4)
@@ -1384,6 +1387,8 @@ def parse_args(argv=None):
     ap.add_argument("--deblock-jobs", action="store_true",
                     help="profiling aid: deblock from host-built edge jobs (vvc355_deblock_batch) instead of the stage driver")
     ap.add_argument("--affine-frac", type=float, default=0.06, help="fraction of the inter CTUs that are affine (+PROF); the metric uses 0.06")
+    ap.add_argument("--inter-frac", type=float, default=0.8, help="fraction of inter CTUs; the metric uses 0.8; 0 = all-intra picture (BASELINE.json configs[1]: the in-order "
+                                                                 "intra pass over every CTU, a dense wavefront)")
     ap.add_argument("--only", type=str, default="", help="comma-separated stage names (profiling aid; default = full chain)")
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="TEST AID: replace the GPU chain by a host sleep of this many ms per step (exercises the launcher, the rendezvous, "
@@ -1403,7 +1408,8 @@ def main(argv=None):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 2 * max(1, args.frames_in_flight))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
-    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES
+    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES, INTER_FRAC
+    INTER_FRAC = args.inter_frac
     SAO_TABLES = not args.sao_jobs
     ALF_TABLES = not args.alf_jobs
     DEBLOCK_JOBS = args.deblock_jobs
@@ -1569,11 +1575,11 @@ def main(argv=None):
             "data": "synthetic",
             "config": {
                 "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
-                            f"({n_ff} independent frame(s) in flight per step, one HIP stream each; per frame 80 % inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
-                            f"{CIIP_FRAC:.0%} of all CTUs combined inter / intra; 20 % intra CTUs reconstructed in decoding order with LFNST / implicit MTS; "
+                            f"({n_ff} independent frame(s) in flight per step, one HIP stream each; per frame {INTER_FRAC:.0%} inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
+                            f"{CIIP_FRAC:.0%} of all CTUs combined inter / intra; {1 - INTER_FRAC:.0%} intra CTUs reconstructed in decoding order with LFNST / implicit MTS; "
                             f"{'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
                             f"stages per step: {', '.join(st.name for st in chain)}",
-                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
+                "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and INTER_FRAC == 0.8 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --inter-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
                 "parallelism": f"{world} independent frame stream(s), one per GPU, no collective; {n_ff} frame(s) in flight per GPU, one HIP stream each, "
                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
             },
