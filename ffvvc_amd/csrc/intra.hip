@@ -321,32 +321,35 @@ __device__ __forceinline__ int pdpc_simple(int val, int x, int y, int pdpc_mode,
     return clip_px<BD>(val + ((wl * (l - val) + wt * (t - val) + 32) >> 6));
 }
 
-// kind: 0 planar, 1 DC (dc = the mean), 2 vertical, 3 horizontal; V = samples per lane and step (4: w >= 4; 1: any block)
-template <int BD, int NT, int V, typename R, typename PX>
-__device__ void pred_simple_q(int tid, PX src, int stride, R top, R left, int w, int h, int kind, int dc, int pdpc_mode)
+// KIND: 0 planar, 1 DC (dc = the mean), 2 vertical, 3 horizontal; V = samples per lane and step (4: w >= 4; 1: any block); PDPC: the
+// position-dependent weights of the block's own mode apply (mode 0 / 1 / 50 / 18 for KIND 0 / 1 / 2 / 3).  All compile-time: a wave
+// that walks blocks one after the other pays for every branch inside these loops.
+template <int BD, int NT, int V, int KIND, bool PDPC, typename R, typename PX>
+__device__ void pred_simple_k(int tid, PX src, int stride, R top, R left, int w, int h, int dc)
 {
     constexpr int LV = V == 4 ? 2 : 0;
+    constexpr int pdpc_mode = KIND == 0 ? 0 : KIND == 1 ? 1 : KIND == 2 ? 50 : 18;
     const int lw = ilog2i(w), lh = ilog2i(h), lq = lw - LV, scale = (lw + lh - 2) >> 2;
-    const int tw = kind == 0 ? top(w) : 0, lhh = kind == 0 ? left(h) : 0;
-    const int tl_top = pdpc_mode >= 18 ? top(-1) : 0, tl_left = pdpc_mode >= 18 ? left(-1) : 0;
+    const int tw = KIND == 0 ? top(w) : 0, lhh = KIND == 0 ? left(h) : 0;
+    const int tl_top = (PDPC && KIND >= 2) ? top(-1) : 0, tl_left = (PDPC && KIND >= 2) ? left(-1) : 0;
     for (int q = tid; q < (h << lq); q += NT) {
         const int y = q >> lq, x0 = (q & ((1 << lq) - 1)) << LV;
         int v[V];
-        const int l = (kind == 0 || kind == 3) ? left(y) : 0;
+        const int l = (KIND == 0 || KIND == 3) ? left(y) : 0;
 #pragma unroll
         for (int e = 0; e < V; e++) {
             const int x = x0 + e;
-            if (kind == 0) {
+            if (KIND == 0) {
                 const int pv = ((h - 1 - y) * top(x) + (y + 1) * lhh) << lw;
                 const int ph = ((w - 1 - x) * l + (x + 1) * tw) << lh;
                 v[e] = (pv + ph + w * h) >> (lw + lh + 1);
-            } else if (kind == 1)
+            } else if (KIND == 1)
                 v[e] = dc;
-            else if (kind == 2)
+            else if (KIND == 2)
                 v[e] = top(x);
             else
                 v[e] = l;
-            if (pdpc_mode >= 0)
+            if (PDPC)
                 v[e] = pdpc_simple<BD>(v[e], x, y, pdpc_mode, scale, top, left, tl_top, tl_left);
         }
         if constexpr (V == 4)
@@ -355,39 +358,52 @@ __device__ void pred_simple_q(int tid, PX src, int stride, R top, R left, int w,
             src.st(x0 + __mul24(stride, y), v[0]);
     }
 }
+template <int BD, int NT, int V, typename R, typename PX>
+__device__ void pred_simple_q(int tid, PX src, int stride, R top, R left, int w, int h, int kind, int dc, bool pdpc)
+{
+    switch (kind * 2 + (pdpc ? 1 : 0)) {
+    case 0: pred_simple_k<BD, NT, V, 0, false>(tid, src, stride, top, left, w, h, dc); break;
+    case 1: pred_simple_k<BD, NT, V, 0, true>(tid, src, stride, top, left, w, h, dc); break;
+    case 2: pred_simple_k<BD, NT, V, 1, false>(tid, src, stride, top, left, w, h, dc); break;
+    case 3: pred_simple_k<BD, NT, V, 1, true>(tid, src, stride, top, left, w, h, dc); break;
+    case 4: pred_simple_k<BD, NT, V, 2, false>(tid, src, stride, top, left, w, h, dc); break;
+    case 5: pred_simple_k<BD, NT, V, 2, true>(tid, src, stride, top, left, w, h, dc); break;
+    case 6: pred_simple_k<BD, NT, V, 3, false>(tid, src, stride, top, left, w, h, dc); break;
+    default: pred_simple_k<BD, NT, V, 3, true>(tid, src, stride, top, left, w, h, dc); break;
+    }
+}
 
 // directional modes: lanes own four samples ALONG the main reference (a row's four for the vertical modes, a column's four for the
 // horizontal ones): they share the row's (column's) offset and fraction, and seven reference samples cover their four windows
-template <int BD, int NT, int V, typename R, typename PX, typename TB>
-__device__ void pred_angular_q(int tid, PX src, int stride, R top, R left, int w, int h, bool vertical,
-                               int c_idx, int angle, int inv, int nscale, int ref_idx, int filter_flag, int need_pdpc, TB tabs)
+// VERT / LUMA / PDPC are compile-time.  A zero fraction needs no case of its own where the reference copies ref[i + 1]: the cubic filter's
+// entry 0 is {0, 64, 0, 0} and the chroma two-tap form with fact = 0 is (32 ref[i + 1] + 16) >> 5 — both give ref[i + 1] exactly (with
+// the smoothing filter fG the reference filters at fact = 0 too).
+template <int BD, int NT, int V, bool VERT, bool LUMA, bool PDPC, typename R, typename PX, typename TB>
+__device__ void pred_angular_k(int tid, PX src, int stride, R top, R left, int w, int h, int angle, int inv, int nscale, int ref_idx, int filter_flag, TB tabs)
 {
     constexpr int LV = V == 4 ? 2 : 0;
     const int base = -(1 + ref_idx);
-    const int n_along = vertical ? w : h, n_across = vertical ? h : w;
+    const int n_along = VERT ? w : h, n_across = VERT ? h : w;
     const int lq = ilog2i(n_along) - LV, lw = ilog2i(w);
-    const R ref = vertical ? top : left, side = vertical ? left : top;
-    const int pd_lim = need_pdpc ? (vertical ? min(w, 3 << nscale) : (3 << nscale)) : 0;
+    const R ref = VERT ? top : left, side = VERT ? left : top;
+    const int pd_lim = PDPC ? (VERT ? min(w, 3 << nscale) : (3 << nscale)) : 0;
     for (int q = tid; q < (n_across << lq); q += NT) {
         // V = 4, vertical: q walks rows of quads (stores are 4-sample row pieces); horizontal: consecutive lanes take consecutive
         // columns.  V = 1: q is the sample's raster index, whatever the direction (row stores stay contiguous).
         int across, a0;
         if (V == 4) {
-            across = vertical ? q >> lq : q & (n_across - 1);
-            a0 = vertical ? (q & ((1 << lq) - 1)) << 2 : (q >> ilog2i(n_across)) << 2;
+            across = VERT ? q >> lq : q & (n_across - 1);
+            a0 = VERT ? (q & ((1 << lq) - 1)) << 2 : (q >> ilog2i(n_across)) << 2;
         } else {
             const int y = q >> lw, x = q & (w - 1);
-            across = vertical ? y : x;
-            a0 = vertical ? x : y;
+            across = VERT ? y : x;
+            a0 = VERT ? x : y;
         }
         const int pos = (1 + ref_idx + across) * angle;
         const int idx = (pos >> 5) + ref_idx, fact = pos & 31;
         const int b = base + a0 + idx;
         int v[V];
-        if (!fact && (c_idx || !filter_flag)) {
-#pragma unroll
-            for (int e = 0; e < V; e++) v[e] = ref(b + 1 + e);
-        } else if (!c_idx) {
+        if (LUMA) {
             const int f = (int)tabs.filt4(filter_flag * 32 + fact);
             const int f0 = (int)(int8_t)f, f1 = (int)(int8_t)(f >> 8), f2 = (int)(int8_t)(f >> 16), f3 = f >> 24;
             int r[V + 3];
@@ -402,36 +418,43 @@ __device__ void pred_angular_q(int tid, PX src, int stride, R top, R left, int w
 #pragma unroll
             for (int e = 0; e < V; e++) v[e] = ((32 - fact) * r[e] + fact * r[e + 1] + 16) >> 5;
         }
-        if (need_pdpc) {
-            if (vertical) {
+        if (PDPC) {
 #pragma unroll
-                for (int e = 0; e < V; e++) {
-                    const int x = a0 + e;
-                    if (x < pd_lim) {
-                        const int l = side(across + ((256 + (x + 1) * inv) >> 9));
-                        v[e] = clip_px<BD>(v[e] + (((l - v[e]) * (32 >> ((x << 1) >> nscale)) + 32) >> 6));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < V; e++) {
-                    const int y = a0 + e;
-                    if (y < pd_lim) {
-                        const int t = side(across + ((256 + (y + 1) * inv) >> 9));
-                        v[e] = clip_px<BD>(v[e] + (((t - v[e]) * (32 >> min(31, (y * 2) >> nscale)) + 32) >> 6));
-                    }
+            for (int e = 0; e < V; e++) {
+                const int p = a0 + e;               // x for the vertical modes, y for the horizontal ones
+                if (p < pd_lim) {
+                    const int s_ = side(across + ((256 + (p + 1) * inv) >> 9));
+                    const int wgt = VERT ? 32 >> ((p << 1) >> nscale) : 32 >> min(31, (p * 2) >> nscale);
+                    v[e] = clip_px<BD>(v[e] + (((s_ - v[e]) * wgt + 32) >> 6));
                 }
             }
         }
         if (V == 1)
-            src.st(vertical ? a0 + __mul24(stride, across) : across + __mul24(stride, a0), v[0]);
-        else if (vertical)
+            src.st(VERT ? a0 + __mul24(stride, across) : across + __mul24(stride, a0), v[0]);
+        else if (VERT)
             src.st4(a0 + __mul24(stride, across), v[0], v[1], v[2], v[3]);
         else {
 #pragma unroll
             for (int e = 0; e < V; e++) src.st(across + __mul24(stride, a0 + e), v[e]);
         }
     }
+}
+template <int BD, int NT, int V, typename R, typename PX, typename TB>
+__device__ void pred_angular_q(int tid, PX src, int stride, R top, R left, int w, int h, bool vertical,
+                               int c_idx, int angle, int inv, int nscale, int ref_idx, int filter_flag, int need_pdpc, TB tabs)
+{
+#define VVC355_ANG(VERT, LUMA, PDPC) pred_angular_k<BD, NT, V, VERT, LUMA, PDPC>(tid, src, stride, top, left, w, h, angle, inv, nscale, ref_idx, filter_flag, tabs)
+    switch ((vertical ? 4 : 0) + (c_idx == 0 ? 2 : 0) + (need_pdpc ? 1 : 0)) {
+    case 0: VVC355_ANG(false, false, false); break;
+    case 1: VVC355_ANG(false, false, true); break;
+    case 2: VVC355_ANG(false, true, false); break;
+    case 3: VVC355_ANG(false, true, true); break;
+    case 4: VVC355_ANG(true, false, false); break;
+    case 5: VVC355_ANG(true, false, true); break;
+    case 6: VVC355_ANG(true, true, false); break;
+    default: VVC355_ANG(true, true, true); break;
+    }
+#undef VVC355_ANG
 }
 
 // MIP (:708-824).  `red` = 16 ints of LDS scratch.
@@ -667,8 +690,8 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         if (w < 4 && (kind == 1 || kind == 3)) {
             if (kind == 1) pred_dc<BD, NT>(tid, src, stride, T, L, w, h, scratch);
             else           pred_vh<BD, NT>(tid, src, stride, L, w, h, false);
-        } else if (quads) pred_simple_q<BD, NT, 4>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc ? mode : -1);
-        else              pred_simple_q<BD, NT, 1>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc ? mode : -1);
+        } else if (quads) pred_simple_q<BD, NT, 4>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc != 0);
+        else              pred_simple_q<BD, NT, 1>(tid, src, stride, T, L, w, h, kind, dc, need_pdpc != 0);
     }
     RPHASE(24);
 #undef RPHASE
