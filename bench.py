@@ -201,106 +201,107 @@ def build_chain(lib, torch, fr):
     ctu_of_gpm = ctu_of[gpm_blk]
     x0, y0 = x0[inter], y0[inter]
     n_blk = len(x0)
-    d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8))
-    mv = rng.integers(-24 * 16, 24 * 16 + 1, size=(n_blk, 4))
-    if not fr.noise:
-        # half of the blocks carry motion that is consistent with the displacement between the two references, up to one sample
-        # and a fraction: their search finds a real minimum (early terminations, BDOF switched off by a low cost); the others
-        # point at unrelated content (full searches, BDOF on)
-        match = rng.random(n_blk) < 0.5
-        mv[match, 2] = mv[match, 0] - 32 + rng.integers(-1, 2, size=match.sum()) * 16 + rng.integers(-3, 4, size=match.sum())
-        mv[match, 3] = mv[match, 1] + 32 + rng.integers(-1, 2, size=match.sum()) * 16 + rng.integers(-3, 4, size=match.sum())
-    ctu_of_blk = ctu_of[inter]
-    bj = []
-    for c, (w, h) in enumerate(fr.dims):
-        sh = 1 if c else 0
-        j = batch.job_array(abi.BipredJob, n_blk)
-        j["dst"] = ptr(rec[c]) + (y0 >> sh) * fr.pitch(rec[c]) + (x0 >> sh) * isz
-        j["dst_stride"] = fr.pitch(rec[c])
-        for r, key in enumerate(("ref0", "ref1")):
-            j[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz        # sample (0, 0) of the picture
-            j[key + "_stride"] = fr.pitch(ref[r][c])
-        j["rec"] = ptr(d_rec) + np.arange(n_blk, dtype=np.int64) * 32
-        j["mv"] = mv
-        j["x"], j["y"], j["w"], j["h"] = x0 >> sh, y0 >> sh, bs >> sh, bs >> sh
-        j["pic_w"], j["pic_h"] = w, h
-        j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
-        j["dmvr"], j["bdof"] = MC_TOOLS & 1, ((MC_TOOLS >> 1) & 1) if c == 0 else 0
-        j["pred_flag"] = 3
-        bj.append(j)
-    # chroma jobs interleaved Cb, Cr, Cb, Cr, ...: the chroma launch predicts the two planes of a sub-block in one wave
-    luma_jobs = bj[0]
-    chroma_jobs = np.empty(2 * n_blk, dtype=bj[1].dtype)
-    chroma_jobs[0::2], chroma_jobs[1::2] = bj[1], bj[2]
-    n_bl, n_bc = len(luma_jobs), len(chroma_jobs)
-    # The job arrays above are the host's expectation only.  What the device runs is written by vvc355_inter_frame_build from the
-    # decoder-side tables: the MvField table (one entry per 4x4 luma block), the reference picture lists, the slice's weight tables
-    # and one 20-byte record per coding unit (here: every 16x16 block is a bi-predicted coding unit of one sub-block).
-    pic_w, pic_h = fr.dims[0]
-    mvf = np.zeros((pic_h // 4 + 1, pic_w // 4), ifc_mvf_dtype())
-    for dy in range(bs // 4):
-        for dx in range(bs // 4):
-            e = mvf[y0 // 4 + dy, x0 // 4 + dx]
-            e["mv"] = mv.reshape(-1, 2, 2)
-            e["pred_flag"] = 3
-            mvf[y0 // 4 + dy, x0 // 4 + dx] = e
-    pus = np.zeros(n_blk, ifc_pu_dtype())
-    pus["x0"], pus["y0"], pus["cb_width"], pus["cb_height"] = x0, y0, bs, bs
-    pus["num_sb_x"] = pus["num_sb_y"] = 1
-    pus["dmvr_flag"], pus["bdof_flag"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
-    pus["first_job"] = np.arange(n_blk)
-    reft = (abi.RefPic * 32)()
-    for l in range(2):
+    if n_blk:            # (an all-intra picture has no regular inter blocks: --inter-frac 0)
+        d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8))
+        mv = rng.integers(-24 * 16, 24 * 16 + 1, size=(n_blk, 4))
+        if not fr.noise:
+            # half of the blocks carry motion that is consistent with the displacement between the two references, up to one sample
+            # and a fraction: their search finds a real minimum (early terminations, BDOF switched off by a low cost); the others
+            # point at unrelated content (full searches, BDOF on)
+            match = rng.random(n_blk) < 0.5
+            mv[match, 2] = mv[match, 0] - 32 + rng.integers(-1, 2, size=match.sum()) * 16 + rng.integers(-3, 4, size=match.sum())
+            mv[match, 3] = mv[match, 1] + 32 + rng.integers(-1, 2, size=match.sum()) * 16 + rng.integers(-3, 4, size=match.sum())
+        ctu_of_blk = ctu_of[inter]
+        bj = []
+        for c, (w, h) in enumerate(fr.dims):
+            sh = 1 if c else 0
+            j = batch.job_array(abi.BipredJob, n_blk)
+            j["dst"] = ptr(rec[c]) + (y0 >> sh) * fr.pitch(rec[c]) + (x0 >> sh) * isz
+            j["dst_stride"] = fr.pitch(rec[c])
+            for r, key in enumerate(("ref0", "ref1")):
+                j[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz        # sample (0, 0) of the picture
+                j[key + "_stride"] = fr.pitch(ref[r][c])
+            j["rec"] = ptr(d_rec) + np.arange(n_blk, dtype=np.int64) * 32
+            j["mv"] = mv
+            j["x"], j["y"], j["w"], j["h"] = x0 >> sh, y0 >> sh, bs >> sh, bs >> sh
+            j["pic_w"], j["pic_h"] = w, h
+            j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
+            j["dmvr"], j["bdof"] = MC_TOOLS & 1, ((MC_TOOLS >> 1) & 1) if c == 0 else 0
+            j["pred_flag"] = 3
+            bj.append(j)
+        # chroma jobs interleaved Cb, Cr, Cb, Cr, ...: the chroma launch predicts the two planes of a sub-block in one wave
+        luma_jobs = bj[0]
+        chroma_jobs = np.empty(2 * n_blk, dtype=bj[1].dtype)
+        chroma_jobs[0::2], chroma_jobs[1::2] = bj[1], bj[2]
+        n_bl, n_bc = len(luma_jobs), len(chroma_jobs)
+        # The job arrays above are the host's expectation only.  What the device runs is written by vvc355_inter_frame_build from the
+        # decoder-side tables: the MvField table (one entry per 4x4 luma block), the reference picture lists, the slice's weight tables
+        # and one 20-byte record per coding unit (here: every 16x16 block is a bi-predicted coding unit of one sub-block).
+        pic_w, pic_h = fr.dims[0]
+        mvf = np.zeros((pic_h // 4 + 1, pic_w // 4), ifc_mvf_dtype())
+        for dy in range(bs // 4):
+            for dx in range(bs // 4):
+                e = mvf[y0 // 4 + dy, x0 // 4 + dx]
+                e["mv"] = mv.reshape(-1, 2, 2)
+                e["pred_flag"] = 3
+                mvf[y0 // 4 + dy, x0 // 4 + dx] = e
+        pus = np.zeros(n_blk, ifc_pu_dtype())
+        pus["x0"], pus["y0"], pus["cb_width"], pus["cb_height"] = x0, y0, bs, bs
+        pus["num_sb_x"] = pus["num_sb_y"] = 1
+        pus["dmvr_flag"], pus["bdof_flag"] = MC_TOOLS & 1, (MC_TOOLS >> 1) & 1
+        pus["first_job"] = np.arange(n_blk)
+        reft = (abi.RefPic * 32)()
+        for l in range(2):
+            for c in range(3):
+                reft[l * 16].plane[c] = ptr(ref[l][c]) + Frame.PAD * fr.pitch(ref[l][c]) + Frame.PAD * isz
+                reft[l * 16].stride[c] = fr.pitch(ref[l][c])
+        d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
+        d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(abi.InterSlice()), np.uint8))
+        d_bl = torch.zeros(luma_jobs.nbytes, dtype=torch.uint8, device="cuda")
+        d_bc = torch.zeros(chroma_jobs.nbytes, dtype=torch.uint8, device="cuda")
+        fr.keep += [d_bl, d_bc]
+        inf = abi.InterFrame()
         for c in range(3):
-            reft[l * 16].plane[c] = ptr(ref[l][c]) + Frame.PAD * fr.pitch(ref[l][c]) + Frame.PAD * isz
-            reft[l * 16].stride[c] = fr.pitch(ref[l][c])
-    d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
-    d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(abi.InterSlice()), np.uint8))
-    d_bl = torch.zeros(luma_jobs.nbytes, dtype=torch.uint8, device="cuda")
-    d_bc = torch.zeros(chroma_jobs.nbytes, dtype=torch.uint8, device="cuda")
-    fr.keep += [d_bl, d_bc]
-    inf = abi.InterFrame()
-    for c in range(3):
-        inf.dst[c], inf.dst_stride[c] = ptr(rec[c]), fr.pitch(rec[c])
-    inf.mvf, inf.refs, inf.pus, inf.slices = ptr(d_mvf), ptr(d_reft), ptr(d_pus), ptr(d_slices)
-    inf.jobs_luma, inf.jobs_chroma, inf.records = ptr(d_bl), ptr(d_bc), ptr(d_rec)
-    inf.mvf_stride, inf.n_pus, inf.n_jobs = pic_w // 4, n_blk, n_blk
-    inf.width, inf.height = pic_w, pic_h
-    inf.hs, inf.vs, inf.chroma_format_idc, inf.pixel_shift = 1, 1, 1, int(isz == 2)
-    d_inf = fr.upload(np.frombuffer(bytes(inf), np.uint8))
-    fr.keep.append(inf)
+            inf.dst[c], inf.dst_stride[c] = ptr(rec[c]), fr.pitch(rec[c])
+        inf.mvf, inf.refs, inf.pus, inf.slices = ptr(d_mvf), ptr(d_reft), ptr(d_pus), ptr(d_slices)
+        inf.jobs_luma, inf.jobs_chroma, inf.records = ptr(d_bl), ptr(d_bc), ptr(d_rec)
+        inf.mvf_stride, inf.n_pus, inf.n_jobs = pic_w // 4, n_blk, n_blk
+        inf.width, inf.height = pic_w, pic_h
+        inf.hs, inf.vs, inf.chroma_format_idc, inf.pixel_shift = 1, 1, 1, int(isz == 2)
+        d_inf = fr.upload(np.frombuffer(bytes(inf), np.uint8))
+        fr.keep.append(inf)
 
-    def check_build(fc, orc, env):
-        got_l, got_c = env.after[ptr(d_bl)].view(luma_jobs.dtype), env.after[ptr(d_bc)].view(chroma_jobs.dtype)
-        return n_bl + n_bc, int((got_l != luma_jobs).sum() + (got_c != chroma_jobs).sum())
+        def check_build(fc, orc, env):
+            got_l, got_c = env.after[ptr(d_bl)].view(luma_jobs.dtype), env.after[ptr(d_bc)].view(chroma_jobs.dtype)
+            return n_bl + n_bc, int((got_l != luma_jobs).sum() + (got_c != chroma_jobs).sum())
 
-    # filled once here as well, so that a profiling run with --only on the prediction stages alone finds valid jobs
-    lib.vvc355_inter_frame_build(None, ptr(d_inf), ctypes.addressof(inf))
-    lib.vvc355_stream_sync(None)
-    chain.append(Stage("inter_job_build", "inter_build_kernel", lambda st: lib.vvc355_inter_frame_build(st, ptr(d_inf), ctypes.addressof(inf)),
-                       n_blk * 3 * ctypes.sizeof(abi.BipredJob), writes=[d_bl, d_bc], check=check_build))
-    inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)
+        # filled once here as well, so that a profiling run with --only on the prediction stages alone finds valid jobs
+        lib.vvc355_inter_frame_build(None, ptr(d_inf), ctypes.addressof(inf))
+        lib.vvc355_stream_sync(None)
+        chain.append(Stage("inter_job_build", "inter_build_kernel", lambda st: lib.vvc355_inter_frame_build(st, ptr(d_inf), ctypes.addressof(inf)),
+                           n_blk * 3 * ctypes.sizeof(abi.BipredJob), writes=[d_bl, d_bc], check=check_build))
+        inter_samples = n_blk * (bs * bs + 2 * (bs // 2) ** 2)
 
-    # luma refines the motion (DMVR) and writes the records; chroma of both planes follows at the refined motion.
-    # algorithmic bytes: two reference samples read + one sample written
-    def check_luma(fc, orc, env):
-        idx = np.nonzero(np.isin(ctu_of_blk, env.picks))[0]
-        recs = env.after[ptr(d_rec)].view(np.int32).reshape(-1, 8)
-        bad = fc.check_bipred(orc, bd, luma_jobs, idx, env.mirror, [env.after[rec_ptrs[0]], None, None], rec_ptrs, pitches, recs, ptr(d_rec))
-        env.stats["dmvr_searched_fraction"] = float(recs[:, 6].mean())
-        env.stats["bdof_applied_fraction"] = float(recs[:, 4].mean())
-        return len(idx), bad
+        # luma refines the motion (DMVR) and writes the records; chroma of both planes follows at the refined motion.
+        # algorithmic bytes: two reference samples read + one sample written
+        def check_luma(fc, orc, env):
+            idx = np.nonzero(np.isin(ctu_of_blk, env.picks))[0]
+            recs = env.after[ptr(d_rec)].view(np.int32).reshape(-1, 8)
+            bad = fc.check_bipred(orc, bd, luma_jobs, idx, env.mirror, [env.after[rec_ptrs[0]], None, None], rec_ptrs, pitches, recs, ptr(d_rec))
+            env.stats["dmvr_searched_fraction"] = float(recs[:, 6].mean())
+            env.stats["bdof_applied_fraction"] = float(recs[:, 4].mean())
+            return len(idx), bad
 
-    def check_chroma(fc, orc, env):
-        idx = np.nonzero(np.isin(np.repeat(ctu_of_blk, 2), env.picks))[0]
-        recs = env.snap(d_rec).view(np.int32).reshape(-1, 8)
-        bad = fc.check_bipred(orc, bd, chroma_jobs, idx, env.mirror, [None, env.after[rec_ptrs[1]], env.after[rec_ptrs[2]]], rec_ptrs, pitches, recs, ptr(d_rec))
-        return len(idx), bad
+        def check_chroma(fc, orc, env):
+            idx = np.nonzero(np.isin(np.repeat(ctu_of_blk, 2), env.picks))[0]
+            recs = env.snap(d_rec).view(np.int32).reshape(-1, 8)
+            bad = fc.check_bipred(orc, bd, chroma_jobs, idx, env.mirror, [None, env.after[rec_ptrs[1]], env.after[rec_ptrs[2]]], rec_ptrs, pitches, recs, ptr(d_rec))
+            return len(idx), bad
 
-    chain.append(Stage("inter_pred_luma_dmvr_bdof", f"bipred_kernel<{bd}, true>", lambda st: lib.vvc355_bipred_batch(st, bd, ptr(d_bl), n_bl),
-                       n_blk * bs * bs * 3 * isz, writes=[rec[0], d_rec], check=check_luma))
-    chain.append(Stage("inter_pred_chroma", f"bipred_chroma_pair_kernel<{bd}>", lambda st: lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc),
-                       n_blk * 2 * (bs // 2) ** 2 * 3 * isz, writes=[rec[1], rec[2]], check=check_chroma))
+        chain.append(Stage("inter_pred_luma_dmvr_bdof", f"bipred_kernel<{bd}, true>", lambda st: lib.vvc355_bipred_batch(st, bd, ptr(d_bl), n_bl),
+                           n_blk * bs * bs * 3 * isz, writes=[rec[0], d_rec], check=check_luma))
+        chain.append(Stage("inter_pred_chroma", f"bipred_chroma_pair_kernel<{bd}>", lambda st: lib.vvc355_bipred_chroma_batch(st, bd, ptr(d_bc), n_bc),
+                           n_blk * 2 * (bs // 2) ** 2 * 3 * isz, writes=[rec[1], rec[2]], check=check_chroma))
 
     if len(xg0):
         # geometric-partition blocks: two uni-directional predictions per component, blended by a 112 x 112 weight mask the job
@@ -526,51 +527,52 @@ def build_chain(lib, torch, fr):
             by_shape.setdefault(lg, []).append(j)
             ctu_by_shape.setdefault(lg, []).append((y0 // cs) * fr.ncx + (x0 // cs))
             windows.append((int(j["coeffs"][0]) // 4, n, j["nzw"].copy(), j["nzh"].copy()))
-    tj, itx_launches = [], []  # (first job, count, log2 size)
-    for lg in sorted(by_shape, reverse=True):
-        j = np.concatenate(by_shape[lg])
-        itx_launches.append((sum(len(t) for t in tj), len(j), lg))
-        tj.append(j)
-    if fr.noise:
-        coeffs = torch.randint(-(1 << 8), 1 << 8, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32)
-    else:
-        # sparse levels with a Laplacian magnitude distribution (about half of them zero): the residual of a coded picture
-        mag = (-torch.log(torch.rand(coeff_off // 4, device="cuda", generator=fr.gen).clamp_min(1e-9)) * 1.1).floor()
-        sign = torch.randint(0, 2, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32) * 2 - 1
-        coeffs = mag.to(torch.int32) * sign
-        del mag, sign
-    # levels exist only inside each block's [0, nzw) x [0, nzh) window (the contract of the nz arguments, vvcdsp.h:118)
-    for (first, n, nzw, nzh) in windows:
-        v = coeffs[first:first + len(nzw) * n * n].view(len(nzw), n, n)
-        ar = torch.arange(n, device="cuda")
-        v *= ((ar[None, None, :] < torch.from_numpy(nzw.astype(np.int64)).cuda()[:, None, None]) &
-              (ar[None, :, None] < torch.from_numpy(nzh.astype(np.int64)).cuda()[:, None, None])).to(torch.int32)
-    fr.keep.append(coeffs)
-    itx_all = np.concatenate(tj)
-    ctu_of_itx = np.concatenate([np.concatenate(ctu_by_shape[lg]) for lg in sorted(by_shape, reverse=True)])
-    itx_all["coeffs"] += coeffs.data_ptr()
-    n_itx = len(itx_all)
-    n_samples = coeff_off // 4
-    jsz = itx_all.dtype.itemsize
+    if by_shape:         # (no transform blocks outside the intra CTUs in an all-intra picture)
+        tj, itx_launches = [], []  # (first job, count, log2 size)
+        for lg in sorted(by_shape, reverse=True):
+            j = np.concatenate(by_shape[lg])
+            itx_launches.append((sum(len(t) for t in tj), len(j), lg))
+            tj.append(j)
+        if fr.noise:
+            coeffs = torch.randint(-(1 << 8), 1 << 8, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32)
+        else:
+            # sparse levels with a Laplacian magnitude distribution (about half of them zero): the residual of a coded picture
+            mag = (-torch.log(torch.rand(coeff_off // 4, device="cuda", generator=fr.gen).clamp_min(1e-9)) * 1.1).floor()
+            sign = torch.randint(0, 2, (coeff_off // 4,), device="cuda", generator=fr.gen, dtype=torch.int32) * 2 - 1
+            coeffs = mag.to(torch.int32) * sign
+            del mag, sign
+        # levels exist only inside each block's [0, nzw) x [0, nzh) window (the contract of the nz arguments, vvcdsp.h:118)
+        for (first, n, nzw, nzh) in windows:
+            v = coeffs[first:first + len(nzw) * n * n].view(len(nzw), n, n)
+            ar = torch.arange(n, device="cuda")
+            v *= ((ar[None, None, :] < torch.from_numpy(nzw.astype(np.int64)).cuda()[:, None, None]) &
+                  (ar[None, :, None] < torch.from_numpy(nzh.astype(np.int64)).cuda()[:, None, None])).to(torch.int32)
+        fr.keep.append(coeffs)
+        itx_all = np.concatenate(tj)
+        ctu_of_itx = np.concatenate([np.concatenate(ctu_by_shape[lg]) for lg in sorted(by_shape, reverse=True)])
+        itx_all["coeffs"] += coeffs.data_ptr()
+        n_itx = len(itx_all)
+        n_samples = coeff_off // 4
+        jsz = itx_all.dtype.itemsize
 
-    # the scaling process (dequant, vvc_intra.c:277-417) is fused into the transform's load stage: flat scaling matrix,
-    # qp 22..37, dependent quantisation on for half of the blocks
-    itx_all["dq_flags"] = 1 | (rng.integers(0, 2, size=n_itx) << 1)
-    itx_all["dq_qp"] = rng.integers(22, 38, size=n_itx)
-    itx_all["log2_matrix_size"], itx_all["dc"] = 1, -1
-    d_itx = fr.upload(itx_all.view(np.uint8))
+        # the scaling process (dequant, vvc_intra.c:277-417) is fused into the transform's load stage: flat scaling matrix,
+        # qp 22..37, dependent quantisation on for half of the blocks
+        itx_all["dq_flags"] = 1 | (rng.integers(0, 2, size=n_itx) << 1)
+        itx_all["dq_qp"] = rng.integers(22, 38, size=n_itx)
+        itx_all["log2_matrix_size"], itx_all["dc"] = 1, -1
+        d_itx = fr.upload(itx_all.view(np.uint8))
 
-    def launch_itx(st):
-        for (first, count, lg) in itx_launches:
-            lib.vvc355_itx_shape_batch(st, bd, ptr(d_itx) + first * jsz, count, lg, lg)
+        def launch_itx(st):
+            for (first, count, lg) in itx_launches:
+                lib.vvc355_itx_shape_batch(st, bd, ptr(d_itx) + first * jsz, count, lg, lg)
 
-    def check_itx(fc, orc, env):
-        env.mirror.add(coeffs.data_ptr(), env.snap(coeffs))
-        idx = np.nonzero(np.isin(ctu_of_itx, env.picks))[0]
-        bad = fc.check_itx(orc, bd, itx_all, idx, env.mirror, [env.before[p_] for p_ in rec_ptrs], [env.after[p_] for p_ in rec_ptrs], rec_ptrs, pitches)
-        return len(idx), bad
+        def check_itx(fc, orc, env):
+            env.mirror.add(coeffs.data_ptr(), env.snap(coeffs))
+            idx = np.nonzero(np.isin(ctu_of_itx, env.picks))[0]
+            bad = fc.check_itx(orc, bd, itx_all, idx, env.mirror, [env.before[p_] for p_ in rec_ptrs], [env.after[p_] for p_ in rec_ptrs], rec_ptrs, pitches)
+            return len(idx), bad
 
-    chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz), writes=rec, check=check_itx))
+        chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz), writes=rec, check=check_itx))
 
     # ---------------------------------------------------------------- transform blocks of the intra CTUs: scaling process (+ LFNST on a
     # fifth of the luma blocks) + inverse transform with the transform types derived on the device (implicit MTS), residuals left
