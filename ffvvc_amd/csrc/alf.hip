@@ -76,25 +76,26 @@ __device__ __forceinline__ int vb_dist(int y, int vb_pos) { return y < vb_pos ? 
 
 // Stage rows [y_base-3, y_base+rows+3) x columns [-8, 136) of the job's source rectangle into LDS as uint16,
 // replicating at the readable-apron limits (ext_*), which is what the reference's alf_prepare_buffer produces.
-template <int BD>
-__device__ __forceinline__ void stage_tile(uint16_t (*tile)[kTileW], const vvc355_alf_job &job, int y_base, int rows, int apron)
+template <int BD, int TW = kTileW, int RA = 3>
+__device__ __forceinline__ void stage_tile(uint16_t (*tile)[TW], const vvc355_alf_job &job, int y_base, int rows, int apron)
 {
     using px_t = typename Px<BD>::type;
     const uint8_t *src = (const uint8_t *)job.src;
     const int w = job.w, h = job.h;
     const int x_min = -min((int)job.ext_l, apron), x_max = w - 1 + min((int)job.ext_r, apron);
     const int y_min = -min((int)job.ext_t, apron), y_max = h - 1 + min((int)job.ext_b, apron);
-    const int nchunk = min(kTileW / 8, (w + 23) >> 3);      // columns -8 .. w+7 only
+    const int nchunk = min(TW / 8, (w + 23) >> 3);      // columns -8 .. w+7 only
     const bool aligned = (((uintptr_t)src | (uintptr_t)job.src_stride) & (sizeof(px_t) * 8 - 1)) == 0;
-    // (wave-uniform base, unsigned per-lane offset) addressing: the base sits three rows and eight samples before the rectangle
-    const uint8_t *src_m = src - 3 * job.src_stride - 8 * (int)sizeof(px_t);
+    // (wave-uniform base, unsigned per-lane offset) addressing: the base sits RA rows and eight samples before the rectangle
+    const uint8_t *src_m = src - RA * job.src_stride - 8 * (int)sizeof(px_t);
 
-    for (int i = threadIdx.x; i < (rows + 6) * nchunk; i += blockDim.x) {
-        const int r = i / nchunk, k = i - r * nchunk;
-        const int y = clip3(y_base + r - 3, y_min, y_max);
+    const uint32_t recip = (65536u + nchunk - 1) / nchunk;          // wave-uniform; i / nchunk == (i * recip) >> 16 for i < 4096, nchunk <= 18
+    for (int i = threadIdx.x; i < (rows + 2 * RA) * nchunk; i += blockDim.x) {
+        const int r = (int)(((uint32_t)i * recip) >> 16), k = i - r * nchunk;
+        const int y = clip3(y_base + r - RA, y_min, y_max);
         const int c0 = k * 8 - kColOff;
         const px_t *row = (const px_t *)(src + (ptrdiff_t)y * job.src_stride);
-        const uint32_t row_m = (uint32_t)__mul24(y + 3, job.src_stride);       // y >= -3
+        const uint32_t row_m = (uint32_t)__mul24(y + RA, job.src_stride);       // y >= -RA
         uint16_t v[8];
         if (aligned && c0 >= 0 && c0 + 8 <= w) {
             if (BD > 8) {
@@ -216,14 +217,12 @@ __device__ __forceinline__ void filter_block_regs(const Win &win, const int (&f)
 // ---------------------------------------------------------------------------------------------- luma kernel
 
 // MODE 0: per-4x4 coefficient/clip arrays (the reference's alf.filter[LUMA] slot).
-// MODE 1: fused classify -> coefficient gather -> filter (the three slots the caller chains, vvc_filter.c:1139-1186).
 // MODE 2: classify only (alf.classify slot): writes class_idx / transpose_idx ints.
+// (The fused form the caller chains per CTB, vvc_filter.c:1139-1186, is alf_ctb_kernel below.)
 template <int BD, int MODE>
 __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__restrict__ jobs)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
-    // fused mode: the CTB's filter set, expanded for the 4 transposes: [transpose][class][tap] = coeff | clip << 16
-    __shared__ __attribute__((aligned(16))) uint32_t ftab[MODE == 1 ? 4 * 25 * 12 : 4];
     const int wg = xcd_chunked(blockIdx.x, gridDim.x);       // an XCD's L2 sees a contiguous run of CTBs (shared aprons)
     const vvc355_alf_job job = jobs[wg >> 2];      // (scalar load_uniform measured 6 % slower here: this kernel is VALU-bound and register-tight)
     const int y_base = (wg & 3) * kStripH;
@@ -231,18 +230,6 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
         return;
     const int rows = min(kStripH, job.h - y_base);
     stage_tile<BD>(tile, job, y_base, rows, 3);
-    if (MODE == 1) {
-        // alf_recon_coeff_and_clip (:383) for every (transpose, class) once per workgroup
-        const int16_t *coeff_set = (const int16_t *)job.coeff;
-        const uint8_t *clip_idx = (const uint8_t *)job.clip, *c2f = (const uint8_t *)job.class_to_filt;
-        for (int e = threadIdx.x; e < 4 * 25 * 12; e += blockDim.x) {
-            const int t = e / 300, r = e - t * 300, cls = r / 12, k = r - cls * 12;
-            const int idx = kAlfPerm[t][k];
-            const int q = gld<uint8_t>(clip_idx + cls * 12 + idx);
-            const int cv = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
-            ftab[e] = (uint32_t)(uint16_t)gld<int16_t>(coeff_set + gld<uint8_t>(c2f + cls) * 12 + idx) | ((uint32_t)cv << 16);
-        }
-    }
     __syncthreads();
 
     const int bx = threadIdx.x & 31, by = threadIdx.x >> 5;
@@ -268,19 +255,9 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
     } else {
         int cls, tr;
         classify_win<BD>(win, yb, vb_pos, cls, tr);
-        if (MODE == 2) {
-            ((int *)job.coeff)[blk] = cls;
-            ((int *)job.clip)[blk] = tr;
-            return;
-        }
-        const uint4 *e = (const uint4 *)&ftab[(tr * 25 + cls) * 12];
-        const uint4 e0 = e[0], e1 = e[1], e2 = e[2];
-        const uint32_t ev[12] = { e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w };
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            f[k] = (int)(int16_t)(ev[k] & 0xffff);
-            c[k] = (int)(ev[k] >> 16);
-        }
+        ((int *)job.coeff)[blk] = cls;
+        ((int *)job.clip)[blk] = tr;
+        return;
     }
 
     uint8_t *dst = (uint8_t *)job.dst;
@@ -309,6 +286,448 @@ __global__ __launch_bounds__(256) void alf_luma_kernel(const vvc355_alf_job *__r
                 sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
                 st_px<BD>(dst + (ptrdiff_t)y * job.dst_stride, x + j, clip_px<BD>(sum + cur));
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- CTB kernel (stage driver)
+//
+// What ff_vvc_alf_filter does for one CTB (vvc_filter.c:1254-1318) in one workgroup per 32-row strip of the CTB: the luma strip
+// (+ 3-sample apron) is staged once and serves the classification, the 7x7 diamond AND the CC-ALF of both chroma components;
+// chroma is read once and written once (4:2:0: CHROMA = true; other formats run the separate chroma / CC kernels).
+//
+//  * Classification without recomputation: a 2x2 "cell" of the subsampled Laplacian grid (:319-343) belongs to the 8x8 windows
+//    of four 4x4 blocks.  Every lane computes the four cells inside its own block once (from its register window), lanes 0..99
+//    the ring of cells around the strip (from the LDS tile); the cells go to LDS as packed 16-bit {V|H, D0|D1} and every block
+//    sums its 4x4 cells from there (:345-380).  16 cells x 2 samples x 2 * 4095 fits 16 bits horizontally at every bit depth;
+//    the vertical sum is packed up to 10 bits and 32-bit at 12.
+//  * Filter without clamps where they cannot bite: alf_clip (:38) with clip = 2^bd (clip index 0: every fixed filter set,
+//    vvc_filter.c:1147-1158, and every APS class without non-linear clipping) never changes |a - cur| < 2^bd, so
+//        sum = sum_k f[k] * (a_k + b_k) - 2 * cur * sum_k f[k]                                  (identical modulo 2^32)
+//    and the tap sums become v_dot2_i32_i16 of the window's own sample pairs against coefficient pairs laid out per column
+//    parity: 16 dot products + one mad for the centre per sample instead of 72 sub / med3 / mad.  The workgroup takes this path
+//    when every (class, tap) of the CTB's filter set has clip index 0 or coefficient 0; otherwise the clamped form runs.
+// what the stage driver's builder leaves per (CTB, chroma component) for the CTB kernel, 64 bytes, fetched with scalar loads
+struct AlfChromaParams {
+    int16_t clip[6];         // clip values of the chroma alternative (what vvc355_alf_job.clip of the chroma job points at)
+    int16_t clamps;          // some tap has a clip value below 2^bd and a non-zero coefficient
+    int16_t cc_on;           // CC-ALF on for this CTB component
+    int16_t f[6];            // chroma coefficients
+    int16_t pad0[2];
+    int16_t g[7];            // CC-ALF coefficients
+    int16_t pad1[9];
+};
+static_assert(sizeof(AlfChromaParams) == 64, "scalar-loaded whole dwords");
+
+static constexpr int kCellRows = kStripH / 2 + 2;      // cell row cr: sample A on strip row 2 * cr - 2
+static constexpr int kCellCols = 34;                   // block columns -1 .. 32 (index = column + 1)
+static constexpr int kCTileW   = 80;                   // 4:2:0 chroma strip: columns -8 .. 71
+static constexpr int kCTileH   = kStripH / 2 + 4;      // rows -2 .. 17
+
+typedef short alf_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(alf_v2s, a), __builtin_bit_cast(alf_v2s, b), acc, false);
+}
+// (low half of a) | (low half of b) << 16, whatever the upper halves hold
+__device__ __forceinline__ uint32_t pk_ll(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+// the same written so that wave-uniform operands stay on the scalar unit
+__device__ __forceinline__ uint32_t upk_ll(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ uint32_t pk_l0(uint32_t a) { return a & 0xffffu; }
+__device__ __forceinline__ uint32_t pk_0l(uint32_t a) { return a << 16; }
+
+// One cell of the Laplacian grid (vvc_filter_template.c:325-343): samples A = (row 1, column ca) and B = (row 2, ca + 1) of the
+// four rows the accessor px(row, column) exposes: 0 = the row above A (A's own row at the virtual boundary, :323-324), 1 = A's
+// row, 2 = B's row, 3 = the row below B (B's own row at the boundary, :321-322).  Returns V | H << 16 and D0 | D1 << 16.
+template <class F>
+__device__ __forceinline__ void grad_cell(F px, int ca, uint32_t &vh, uint32_t &dd)
+{
+    const int cb = ca + 1;
+    const unsigned a2 = px(1, ca) << 1, b2 = px(2, cb) << 1;
+    const unsigned v  = __sad(a2, px(0, ca) + px(2, ca), __sad(b2, px(1, cb) + px(3, cb), 0u));
+    const unsigned h  = __sad(a2, px(1, ca - 1) + px(1, ca + 1), __sad(b2, px(2, cb - 1) + px(2, cb + 1), 0u));
+    const unsigned d0 = __sad(a2, px(0, ca - 1) + px(2, ca + 1), __sad(b2, px(1, cb - 1) + px(3, cb + 1), 0u));
+    const unsigned d1 = __sad(a2, px(0, ca + 1) + px(2, ca - 1), __sad(b2, px(1, cb + 1) + px(3, cb - 1), 0u));
+    vh = v | (h << 16);
+    dd = d0 | (d1 << 16);
+}
+
+// 7x7 diamond without clamps on one 4x4 block from the register window (KIND as in filter_block_regs).  ev[k] holds tap k's
+// coefficient in its low half.  Window column c = 4 + j of row r sits in dword c >> 1; per column parity the taps of a row pair
+// up with the dwords as they are: even c: row 0 (c-4 c-3)(c-2 c-1)(c c+1)(c+2 c+3), odd c: (c-3 c-2)(c-1 c)(c+1 c+2)(c+3 c+4), ...
+template <int BD, int KIND>
+__device__ __forceinline__ void filter_block_fast(const Win &win, const uint32_t (&ev)[12], uint8_t *drow, int dst_stride)
+{
+    int fsum = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) fsum += (int)(int16_t)(ev[k] & 0xffff);
+    const int cen = -2 * fsum;                      // |cen| < 2^20: a 24-bit multiply is exact
+    uint32_t outp[4][2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+        uint32_t z0[4], p1[3], m1[3], p2[2], m2[2], p3;
+        if (par == 0) {
+            z0[0] = pk_0l(ev[9]); z0[1] = pk_ll(ev[10], ev[11]); z0[2] = pk_0l(ev[11]); z0[3] = pk_ll(ev[10], ev[9]);
+            p1[0] = pk_ll(ev[8], ev[7]); p1[1] = pk_ll(ev[6], ev[5]); p1[2] = pk_l0(ev[4]);
+            m1[0] = pk_ll(ev[4], ev[5]); m1[1] = pk_ll(ev[6], ev[7]); m1[2] = pk_l0(ev[8]);
+            p2[0] = pk_0l(ev[3]); p2[1] = pk_ll(ev[2], ev[1]);
+            m2[0] = pk_0l(ev[1]); m2[1] = pk_ll(ev[2], ev[3]);
+            p3 = pk_l0(ev[0]);
+        } else {
+            z0[0] = pk_ll(ev[9], ev[10]); z0[1] = pk_l0(ev[11]); z0[2] = pk_ll(ev[11], ev[10]); z0[3] = pk_l0(ev[9]);
+            p1[0] = pk_0l(ev[8]); p1[1] = pk_ll(ev[7], ev[6]); p1[2] = pk_ll(ev[5], ev[4]);
+            m1[0] = pk_0l(ev[4]); m1[1] = pk_ll(ev[5], ev[6]); m1[2] = pk_ll(ev[7], ev[8]);
+            p2[0] = pk_ll(ev[3], ev[2]); p2[1] = pk_l0(ev[1]);
+            m2[0] = pk_ll(ev[1], ev[2]); m2[1] = pk_l0(ev[3]);
+            p3 = pk_0l(ev[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int dist = KIND == 0 ? 3 : KIND == 1 ? 3 - i : i;
+            const int r0 = 3 + i, d1 = dist < 1 ? dist : 1, d2 = dist < 2 ? dist : 2, d3 = dist < 3 ? dist : 3;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int c = 4 + par + 2 * jj, m = c >> 1;
+                const int b0 = par ? m - 1 : m - 2, b2 = par ? m : m - 1;
+                int sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) sum = sdot2(win.d[r0][b0 + q], z0[q], sum);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    sum = sdot2(win.d[r0 + d1][m - 1 + q], p1[q], sum);
+                    sum = sdot2(win.d[r0 - d1][m - 1 + q], m1[q], sum);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    sum = sdot2(win.d[r0 + d2][b2 + q], p2[q], sum);
+                    sum = sdot2(win.d[r0 - d2][b2 + q], m2[q], sum);
+                }
+                sum = sdot2(win.d[r0 + d3][m], p3, sum);
+                sum = sdot2(win.d[r0 - d3][m], p3, sum);
+                const int cur = win.at(r0, c);
+                sum = mad24(cen, cur, sum);
+                const int o = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+                outp[i][jj] = par ? outp[i][jj] | ((uint32_t)o << 16) : (uint32_t)o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint8_t *d = drow + (ptrdiff_t)i * dst_stride;
+        if (BD > 8)
+            gst<uint2>(d, make_uint2(outp[i][0], outp[i][1]));
+        else
+            gst<uint32_t>(d, __builtin_amdgcn_perm(outp[i][1], outp[i][0], 0x06040200u));
+    }
+}
+
+// chroma 5x5 diamond (:137) on four consecutive samples x .. x + 3 of one row from a 5-row x 8-column register window (rows
+// -d2, -d1, 0, +d1, +d2 already folded onto the virtual boundary; columns x - 2 .. x + 5, two per dword); clamped form
+template <int BD>
+__device__ __forceinline__ void chroma_quad(const uint32_t (&win)[5][4], const int (&f)[6], const int (&c)[6], int dist, int (&out)[4])
+{
+#define WPX(r, c) ((int)((win[r][(c) >> 1] >> (((c) & 1) * 16)) & 0xffff))
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cur = WPX(2, j + 2);
+        int sum = 0;
+        sum = mad24(f[0], clamp_sym(WPX(4, j + 2) - cur, c[0]) + clamp_sym(WPX(0, j + 2) - cur, c[0]), sum);     // (2, 0)
+        sum = mad24(f[1], clamp_sym(WPX(3, j + 3) - cur, c[1]) + clamp_sym(WPX(1, j + 1) - cur, c[1]), sum);     // (1, 1)
+        sum = mad24(f[2], clamp_sym(WPX(3, j + 2) - cur, c[2]) + clamp_sym(WPX(1, j + 2) - cur, c[2]), sum);     // (1, 0)
+        sum = mad24(f[3], clamp_sym(WPX(3, j + 1) - cur, c[3]) + clamp_sym(WPX(1, j + 3) - cur, c[3]), sum);     // (1, -1)
+        sum = mad24(f[4], clamp_sym(WPX(2, j + 4) - cur, c[4]) + clamp_sym(WPX(2, j) - cur, c[4]), sum);         // (0, 2)
+        sum = mad24(f[5], clamp_sym(WPX(2, j + 3) - cur, c[5]) + clamp_sym(WPX(2, j + 1) - cur, c[5]), sum);     // (0, 1)
+        sum = dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7;
+        out[j] = clip_px<BD>(sum + cur);
+    }
+#undef WPX
+}
+
+// the same without clamps (every clip value 2^bd, or a zero coefficient): 9 dot products + the centre per sample
+template <int BD>
+__device__ __forceinline__ void chroma_quad_fast(const uint32_t (&win)[5][4], const int (&f)[6], int dist, int (&out)[4])
+{
+    const int cen = -2 * (f[0] + f[1] + f[2] + f[3] + f[4] + f[5]);
+    const uint32_t F0 = f[0], F1 = f[1], F2 = f[2], F3 = f[3], F4 = f[4], F5 = f[5];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = j + 2, m = c >> 1;
+        int sum = 0;
+        if (!(c & 1)) {                         // dwords m-1 (c-2 c-1), m (c c+1), m+1 (c+2 c+3)
+            sum = sdot2(win[2][m - 1], upk_ll(F4, F5), sum); sum = sdot2(win[2][m], pk_0l(F5), sum); sum = sdot2(win[2][m + 1], pk_l0(F4), sum);
+            sum = sdot2(win[3][m - 1], pk_0l(F3), sum); sum = sdot2(win[3][m], upk_ll(F2, F1), sum);
+            sum = sdot2(win[1][m - 1], pk_0l(F1), sum); sum = sdot2(win[1][m], upk_ll(F2, F3), sum);
+            sum = sdot2(win[4][m], pk_l0(F0), sum); sum = sdot2(win[0][m], pk_l0(F0), sum);
+        } else {                                // dwords m-1 (c-3 c-2), m (c-1 c), m+1 (c+1 c+2)
+            sum = sdot2(win[2][m - 1], pk_0l(F4), sum); sum = sdot2(win[2][m], pk_l0(F5), sum); sum = sdot2(win[2][m + 1], upk_ll(F5, F4), sum);
+            sum = sdot2(win[3][m], upk_ll(F3, F2), sum); sum = sdot2(win[3][m + 1], pk_l0(F1), sum);
+            sum = sdot2(win[1][m], upk_ll(F1, F2), sum); sum = sdot2(win[1][m + 1], pk_l0(F3), sum);
+            sum = sdot2(win[4][m], pk_0l(F0), sum); sum = sdot2(win[0][m], pk_0l(F0), sum);
+        }
+        const int cur = (int)((win[2][m] >> ((c & 1) * 16)) & 0xffff);
+        sum = mad24(cen, cur, sum);
+        out[j] = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+    }
+}
+
+template <int BD, bool CHROMA>
+__global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__restrict__ luma_jobs, const vvc355_alf_job *__restrict__ chroma_jobs,
+                                                      const vvc355_alf_job *__restrict__ cc_jobs, int log2_strips)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
+    __shared__ __attribute__((aligned(16))) uint32_t ftab[25 * 12];             // [class][tap] = coeff | clip << 16 (untransposed)
+    __shared__ __attribute__((aligned(16))) uint4 cells[kCellRows][kCellCols];   // {left cell V|H, D0|D1, right cell V|H, D0|D1} of a block
+    __shared__ __attribute__((aligned(16))) uint16_t ctile[CHROMA ? 2 : 1][CHROMA ? kCTileH : 1][kCTileW];
+    const int wg = xcd_chunked(blockIdx.x, gridDim.x);
+    const int ctb = wg >> log2_strips;
+    const vvc355_alf_job job = load_uniform(luma_jobs + ctb);
+    const int y_base = (wg & ((1 << log2_strips) - 1)) * kStripH;
+    if (y_base >= job.h)
+        return;
+    const int rows = min(kStripH, job.h - y_base);
+    // the CTB's filter set: every class's filter (class_to_filt resolved) with its clip values; does any tap clamp?
+    int clamps = 0;
+    {
+        const int16_t *coeff_set = (const int16_t *)job.coeff;
+        const uint8_t *clip_idx = (const uint8_t *)job.clip, *c2f = (const uint8_t *)job.class_to_filt;
+        for (int e = threadIdx.x; e < 25 * 12; e += blockDim.x) {
+            const int cls = (e * 5462) >> 16, k = e - cls * 12;               // e / 12 for e < 300
+            const int q = gld<uint8_t>(clip_idx + e);
+            const int cv = 1 << (BD - (q == 0 ? 0 : 2 * q + 1));       // {2^bd, 2^(bd-3), 2^(bd-5), 2^(bd-7)}
+            const int fv = gld<int16_t>(coeff_set + gld<uint8_t>(c2f + cls) * 12 + k);
+            clamps |= (q != 0) & (fv != 0);
+            ftab[e] = (uint32_t)(uint16_t)fv | ((uint32_t)cv << 16);
+        }
+    }
+    stage_tile<BD>(tile, job, y_base, rows, 3);
+    if (CHROMA) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const vvc355_alf_job cj = load_uniform(chroma_jobs + 2 * ctb + c);
+            stage_tile<BD, kCTileW, 2>(ctile[c], cj, y_base >> 1, rows >> 1, 2);
+        }
+    }
+    const bool noclip = !__syncthreads_or(clamps);
+
+    const int bx = threadIdx.x & 31, by = threadIdx.x >> 5;
+    const int x = bx * 4, yl = by * 4, yb = y_base + yl;
+    const bool active = x < job.w && yl < rows;
+    const int vb_pos = job.vb_pos;
+
+    Win win;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint2 *p = (const uint2 *)&tile[yl + r][x + kColOff - 4];
+        const uint2 a = p[0], b = p[1], c = p[2];
+        win.d[r][0] = a.x; win.d[r][1] = a.y; win.d[r][2] = b.x; win.d[r][3] = b.y; win.d[r][4] = c.x; win.d[r][5] = c.y;
+    }
+
+    // ---- Laplacian cells: the four inside this lane's block (cell rows 2 * by + 1, + 2; sample A on window rows 3 and 5) ...
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int ra = 3 + 2 * q, ya = yb + 2 * q;
+            const bool fold_up = ya == vb_pos, fold_dn = ya == vb_pos - 2;
+            uint32_t up[6], dn[6];
+#pragma unroll
+            for (int m = 1; m < 5; m++) {
+                up[m] = fold_up ? win.d[ra][m] : win.d[ra - 1][m];
+                dn[m] = fold_dn ? win.d[ra + 1][m] : win.d[ra + 2][m];
+            }
+            auto px = [&](int r, int c) -> unsigned {
+                const uint32_t v = r == 0 ? up[c >> 1] : r == 1 ? win.d[ra][c >> 1] : r == 2 ? win.d[ra + 1][c >> 1] : dn[c >> 1];
+                return (v >> ((c & 1) * 16)) & 0xffffu;
+            };
+            uint4 e;
+            grad_cell(px, 4, e.x, e.y);
+            grad_cell(px, 6, e.z, e.w);
+            cells[2 * by + 1 + q][bx + 1] = e;
+        }
+    }
+    // ... and the ring around the strip, from the tile: cell row 0, cell row ncr + 1, block column -1, block column w / 4
+    {
+        const int ncr = rows >> 1, nbx = job.w >> 2;
+        const int e = threadIdx.x;
+        if (e < 68 + 2 * ncr) {
+            int cr, bc;
+            if (e < 34)            { cr = 0; bc = e - 1; }
+            else if (e < 68)       { cr = ncr + 1; bc = e - 35; }
+            else if (e < 68 + ncr) { cr = e - 67; bc = -1; }
+            else                   { cr = e - 67 - ncr; bc = nbx; }
+            const int ya = y_base - 2 + 2 * cr, ta = 2 * cr + 1;
+            const int rsel[4] = { ya == vb_pos ? ta : ta - 1, ta, ta + 1, ya == vb_pos - 2 ? ta + 1 : ta + 2 };
+            auto px = [&](int r, int c) -> unsigned { return tile[rsel[r]][c]; };
+            uint4 v;
+            grad_cell(px, 4 * bc + kColOff, v.x, v.y);
+            grad_cell(px, 4 * bc + kColOff + 2, v.z, v.w);
+            cells[cr][bc + 1] = v;
+        }
+    }
+    __syncthreads();
+
+    if (active) {
+        // ---- class and transpose of the block from its 4 x 4 cells (:345-380)
+        int first = 0, last = 4, ac = 2;
+        if (yb + 4 == vb_pos) { last = 3; ac = 3; }
+        else if (yb == vb_pos) { first = 1; ac = 3; }
+        int sum[4] = { 0, 0, 0, 0 };
+        uint32_t svh = 0, sdd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 *row = &cells[2 * by + i][bx];
+            const uint2 l = *(const uint2 *)&row[0].z;          // right cell of the block on the left
+            const uint4 o = row[1];
+            const uint2 r = *(const uint2 *)&row[2].x;          // left cell of the block on the right
+            const uint32_t hvh = l.x + o.x + o.z + r.x, hdd = l.y + o.y + o.w + r.y;     // halves stay below 2^16: no carry between them
+            const bool on = i >= first && i < last;
+            if (BD <= 10) {
+                svh += on ? hvh : 0u;
+                sdd += on ? hdd : 0u;
+            } else if (on) {
+                sum[0] += hvh & 0xffff; sum[1] += hvh >> 16; sum[2] += hdd & 0xffff; sum[3] += hdd >> 16;
+            }
+        }
+        if (BD <= 10) { sum[0] = svh & 0xffff; sum[1] = svh >> 16; sum[2] = sdd & 0xffff; sum[3] = sdd >> 16; }
+        int cls, tr;
+        block_class<BD>(sum, ac, cls, tr);
+
+        // alf_recon_coeff_and_clip (:383): tap k of the block = entry kAlfPerm[transpose][k] of the class's filter; the four
+        // permutations as 4-bit fields (taps 0..7 | taps 8..11)
+        uint32_t ev[12];
+        {
+            constexpr uint32_t PL[4] = { 0x76543210u, 0x7b518a49u, 0x56781230u, 0x5b734a89u }, PH[4] = { 0xba98u, 0x6203u, 0xba94u, 0x6201u };
+            const uint32_t pl = tr == 0 ? PL[0] : tr == 1 ? PL[1] : tr == 2 ? PL[2] : PL[3];
+            const uint32_t ph = tr == 0 ? PH[0] : tr == 1 ? PH[1] : tr == 2 ? PH[2] : PH[3];
+            const uint32_t *row = &ftab[cls * 12];
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                ev[k] = row[((k < 8 ? pl : ph) >> (4 * (k & 7))) & 15];
+        }
+
+        uint8_t *dst = (uint8_t *)job.dst;
+        uint8_t *drow = dst + row_off(yb, job.dst_stride) + x * (BD > 8 ? 2 : 1);
+        // rows of this block closer than 3 to the virtual boundary fold their taps
+        const bool near_vb = vb_dist(yb, vb_pos) < 3 || vb_dist(yb + 3, vb_pos) < 3 || (yb < vb_pos && yb + 3 >= vb_pos);
+        const int kind = !near_vb ? 0 : yb + 4 == vb_pos ? 1 : yb == vb_pos ? 2 : 3;
+        if (noclip && kind < 3) {
+            if (kind == 0)      filter_block_fast<BD, 0>(win, ev, drow, job.dst_stride);
+            else if (kind == 1) filter_block_fast<BD, 1>(win, ev, drow, job.dst_stride);
+            else                filter_block_fast<BD, 2>(win, ev, drow, job.dst_stride);
+        } else {
+            // clamped form, any boundary position: one block row at a time from the tile, tap rows folded onto the virtual boundary
+            // when they are fetched (:80-96), so one body serves every row
+            int f[12], c[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                f[k] = (int)(int16_t)(ev[k] & 0xffff);
+                c[k] = (int)(ev[k] >> 16);
+            }
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                const int dist = vb_dist(yb + i, vb_pos), tr0 = yl + i + 3;
+                const int d1 = min(1, dist), d2 = min(2, dist), d3 = min(3, dist);
+                const int rr[7] = { tr0 - d3, tr0 - d2, tr0 - d1, tr0, tr0 + d1, tr0 + d2, tr0 + d3 };
+                uint32_t R[7][6];
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    const uint2 *p = (const uint2 *)&tile[rr[r]][x + kColOff - 4];
+                    const uint2 a = p[0], b = p[1], cc = p[2];
+                    R[r][0] = a.x; R[r][1] = a.y; R[r][2] = b.x; R[r][3] = b.y; R[r][4] = cc.x; R[r][5] = cc.y;
+                }
+#define RPX(r, q) ((int)((R[r][(q) >> 1] >> (((q) & 1) * 16)) & 0xffff))
+                int out[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int cur = RPX(3, 4 + j);
+                    int sum = 0;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        const int dy = kLumaTap[k][0], dx = kLumaTap[k][1];
+                        sum = mad24(f[k], clamp_sym(RPX(3 + dy, 4 + j + dx) - cur, c[k]) + clamp_sym(RPX(3 - dy, 4 + j - dx) - cur, c[k]), sum);
+                    }
+                    out[j] = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+                }
+#undef RPX
+                uint8_t *d = drow + row_off(i, job.dst_stride);
+                if (BD > 8)
+                    gst<uint2>(d, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
+                else
+                    gst<uint32_t>(d, out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24));
+            }
+        }
+    }
+
+    if (CHROMA) {
+        // ---- 4:2:0 chroma of the strip: lane = four consecutive samples of one row, Cb then Cr; the co-located luma for CC-ALF
+        // (:223) comes from the luma tile, whose replication at unreadable sides is the padded buffer's (vvc_filter.c:1105-1137)
+        const int cyl = threadIdx.x >> 4, cx = (threadIdx.x & 15) * 4;
+        if (cyl >= (rows >> 1) || cx >= (job.w >> 1))
+            return;
+        const int y = (y_base >> 1) + cyl;
+        // luma rows around row 2 * y (tile row 2 * cyl + 3) as CC-ALF folds them onto the luma virtual boundary (:233-241)
+        const int ly = 2 * y;
+        int up = -1, dn = 1, dn2 = 2;
+        if (ly == vb_pos - 2 || ly == vb_pos + 1) dn2 = 1;
+        else if (ly == vb_pos - 1 || ly == vb_pos) up = dn = dn2 = 0;
+        const int lt = 2 * cyl + 3;
+        // dwords (2cx-2 2cx-1) .. (2cx+6 2cx+7) of the centre row and of the row below; the even columns' dwords of the other two
+        uint32_t lc[5], ld[5], lu[4], l2[4];
+        {
+            const uint32_t *rc = (const uint32_t *)&tile[lt][2 * cx + kColOff - 2], *rd = (const uint32_t *)&tile[lt + dn][2 * cx + kColOff - 2];
+            const uint32_t *ru = (const uint32_t *)&tile[lt + up][2 * cx + kColOff], *r2 = (const uint32_t *)&tile[lt + dn2][2 * cx + kColOff];
+#pragma unroll
+            for (int m = 0; m < 5; m++) { lc[m] = rc[m]; ld[m] = rd[m]; }
+#pragma unroll
+            for (int m = 0; m < 4; m++) { lu[m] = ru[m]; l2[m] = r2[m]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const vvc355_alf_job cj = load_uniform(chroma_jobs + 2 * ctb + c);
+            const AlfChromaParams P = load_uniform((const AlfChromaParams *)cj.clip);      // the stage driver's block: all scalar
+            int f[6], cl[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { f[k] = P.f[k]; cl[k] = P.clip[k]; }
+            const bool cclamps = P.clamps != 0;
+            const int dist = vb_dist(y, cj.vb_pos), tr0 = cyl + 2;
+            const int d1 = min(1, dist), d2 = min(2, dist);
+            uint32_t w5[5][4];
+            {
+                const int rr[5] = { tr0 - d2, tr0 - d1, tr0, tr0 + d1, tr0 + d2 };
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    const uint32_t *p = (const uint32_t *)&ctile[c][rr[r]][cx + kColOff - 2];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) w5[r][m] = p[m];
+                }
+            }
+            int out[4];
+            if (cclamps) chroma_quad<BD>(w5, f, cl, dist, out);
+            else         chroma_quad_fast<BD>(w5, f, dist, out);
+            if (P.cc_on) {
+                int g[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) g[k] = P.g[k];
+                const uint32_t G0 = g[0], G1 = g[1], G2 = g[2], G3 = g[3], G4 = g[4], G5 = g[5], G6 = g[6];
+                const int gcen = -(g[0] + g[1] + g[2] + g[3] + g[4] + g[5] + g[6]);
+                const uint32_t k_c0 = pk_0l(G1), k_c1 = pk_0l(G2), k_d0 = pk_0l(G3), k_d1 = upk_ll(G4, G5), k_u = pk_l0(G0), k_2 = pk_l0(G6);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int s = sdot2(lc[j], k_c0, 0);
+                    s = sdot2(lc[j + 1], k_c1, s);
+                    s = sdot2(ld[j], k_d0, s);
+                    s = sdot2(ld[j + 1], k_d1, s);
+                    s = sdot2(lu[j], k_u, s);
+                    s = sdot2(l2[j], k_2, s);
+                    s = mad24(gcen, (int)(lc[j + 1] & 0xffff), s);
+                    s = clip3((s + 64) >> 7, -(1 << (BD - 1)), (1 << (BD - 1)) - 1);
+                    out[j] = clip_px<BD>(out[j] + s);
+                }
+            }
+            uint8_t *d = (uint8_t *)cj.dst + row_off(y, cj.dst_stride);
+            if (BD > 8)
+                gst<uint2>(d + cx * 2, make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
+            else
+                gst<uint32_t>(d + cx, out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24));
         }
     }
 }
@@ -497,7 +916,7 @@ __device__ static const int16_t kAlfZeroSet[25 * 12] = { 0 };
 // jobs and two CC-ALF jobs.  edges[] (:1264-1278) become ext_* = 0 (replicate) / 3 (read the neighbour in place).
 template <int BD>
 __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int n_ctbs, vvc355_alf_job *luma, vvc355_alf_job *chroma,
-                                 vvc355_alf_job *cc, int16_t *clips)
+                                 vvc355_alf_job *cc, AlfChromaParams *params)
 {
     const vvc355_alf_frame F = load_uniform(frame);       // scalar loads, once: the fields are read dozens of times
     const vvc355_alf_frame *fp = &F;
@@ -558,20 +977,23 @@ __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int
         j.dst_stride = fp->dst_stride[c]; j.src_stride = fp->src_stride[c];
         j.w = (int16_t)w; j.h = (int16_t)h; j.vb_pos = (int16_t)((ctb_size >> vs) - 2);
         j.class_to_filt = 0; j.hs = j.vs = 0;
-        int16_t *cl = clips + (2 * rs + c - 1) * 8;
+        AlfChromaParams P = {};
         if (alf.ctb_flag[c]) {
             const int idx = alf.alt_idx[c - 1];
             const uint8_t *ci = (const uint8_t *)sl->chroma_clip_idx + idx * 6;
+            const int16_t *cf = (const int16_t *)sl->chroma_coeff + idx * 6;
             for (int k = 0; k < 6; k++) {
                 const int q = ci[k];
-                cl[k] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));      // alf_clip_from_idx (:1188)
+                P.clip[k] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));      // alf_clip_from_idx (:1188)
+                P.f[k] = cf[k];
+                P.clamps |= q != 0 && cf[k] != 0;
             }
             j.coeff = sl->chroma_coeff + idx * 12;
         } else {
-            for (int k = 0; k < 6; k++) cl[k] = 0;
             j.coeff = (uint64_t)kAlfZeroSet;
         }
-        j.clip = (uint64_t)cl;
+        AlfChromaParams *pp = params + (2 * rs + c - 1);
+        j.clip = (uint64_t)pp->clip;
         chroma[2 * rs + c - 1] = j;
         // ---- CC-ALF: alf_filter_cc (:1212) on the co-located luma
         const uint64_t cc_set = sl->cc_coeff[c - 1];
@@ -580,6 +1002,9 @@ __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int
         j.src_stride = fp->src_stride[0];
         j.coeff = on ? cc_set + (alf.cc_idc[c - 1] - 1) * 14 : (uint64_t)kAlfZeroSet;
         j.clip = 0;
+        P.cc_on = on;
+        for (int k = 0; k < 7; k++) P.g[k] = on ? ((const int16_t *)j.coeff)[k] : 0;
+        *pp = P;
         j.w = (int16_t)(on ? w : 0); j.h = (int16_t)(on ? h : 0);
         j.vb_pos = (int16_t)(ctb_size - 4);
         j.hs = (int8_t)hs; j.vs = (int8_t)vs;
@@ -594,9 +1019,22 @@ static void launch_luma(int bd, int mode, const vvc355_alf_job *jobs, int n, hip
     if (n <= 0) return;
     const dim3 grid(n * 4), block(256);
     VVC355_BD_DISPATCH(bd, {
-        if (mode == 0)      hipLaunchKernelGGL((alf_luma_kernel<BD, 0>), grid, block, 0, st, jobs);
-        else if (mode == 1) hipLaunchKernelGGL((alf_luma_kernel<BD, 1>), grid, block, 0, st, jobs);
-        else                hipLaunchKernelGGL((alf_luma_kernel<BD, 2>), grid, block, 0, st, jobs);
+        if (mode == 0) hipLaunchKernelGGL((alf_luma_kernel<BD, 0>), grid, block, 0, st, jobs);
+        else           hipLaunchKernelGGL((alf_luma_kernel<BD, 2>), grid, block, 0, st, jobs);
+    });
+    HIP_CHECK(hipGetLastError());
+}
+
+// the CTB kernel: luma (fused classify + gather + filter) of n rectangles of at most max_h rows; with chroma / cc job arrays (two per
+// rectangle, 4:2:0) it also filters both chroma components and applies CC-ALF
+static void launch_ctb(int bd, const vvc355_alf_job *luma, const vvc355_alf_job *chroma, const vvc355_alf_job *cc, int n, hipStream_t st, int max_h = 128)
+{
+    if (n <= 0) return;
+    const int log2_strips = max_h <= kStripH ? 0 : max_h <= 2 * kStripH ? 1 : 2;
+    const dim3 grid(n << log2_strips), block(256);
+    VVC355_BD_DISPATCH(bd, {
+        if (chroma) hipLaunchKernelGGL((alf_ctb_kernel<BD, true>), grid, block, 0, st, luma, chroma, cc, log2_strips);
+        else        hipLaunchKernelGGL((alf_ctb_kernel<BD, false>), grid, block, 0, st, luma, chroma, cc, log2_strips);
     });
     HIP_CHECK(hipGetLastError());
 }
@@ -636,7 +1074,8 @@ extern "C" {
 void vvc355_alf_luma_batch(void *stream, int bd, int fused, const vvc355_alf_job *jobs_dev, int n_jobs)
 {
     if (n_jobs <= 0) return;
-    launch_luma(bd, fused ? 1 : 0, jobs_dev, n_jobs, (hipStream_t)stream);
+    if (fused) launch_ctb(bd, jobs_dev, nullptr, nullptr, n_jobs, (hipStream_t)stream);
+    else       launch_luma(bd, 0, jobs_dev, n_jobs, (hipStream_t)stream);
 }
 void vvc355_alf_chroma_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, int n_jobs)
 {
@@ -652,7 +1091,7 @@ void vvc355_alf_cc_batch(void *stream, int bd, const vvc355_alf_job *jobs_dev, i
 // ---- ALF stage driver
 size_t vvc355_alf_frame_work_bytes(int n_ctbs)
 {
-    return (size_t)n_ctbs * (5 * sizeof(vvc355_alf_job) + 2 * 8 * sizeof(int16_t));
+    return (size_t)n_ctbs * (5 * sizeof(vvc355_alf_job) + 2 * sizeof(AlfChromaParams));
 }
 
 void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev)
@@ -664,14 +1103,19 @@ void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_d
         abort();
     }
     vvc355_alf_job *luma = (vvc355_alf_job *)work_dev, *chroma = luma + n, *cc = chroma + 2 * n;
-    int16_t *clips = (int16_t *)(cc + 2 * n);
+    AlfChromaParams *params = (AlfChromaParams *)(cc + 2 * n);
     hipStream_t st = (hipStream_t)stream;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, clips));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, params));
     HIP_CHECK(hipGetLastError());
-    launch_luma(bd, 1, luma, n, st);
-    if (frame_host->n_comp >= 3) {
-        launch_chroma(bd, chroma, 2 * n, st, (1 << frame_host->ctb_log2) >> frame_host->vs);
-        launch_cc(bd, cc, 2 * n, st);
+    const int ctb_size = 1 << frame_host->ctb_log2;
+    if (frame_host->n_comp >= 3 && frame_host->hs == 1 && frame_host->vs == 1) {
+        launch_ctb(bd, luma, chroma, cc, n, st, ctb_size);         // 4:2:0: one kernel, every plane read once and written once
+    } else {
+        launch_ctb(bd, luma, nullptr, nullptr, n, st, ctb_size);
+        if (frame_host->n_comp >= 3) {
+            launch_chroma(bd, chroma, 2 * n, st, ctb_size >> frame_host->vs);
+            launch_cc(bd, cc, 2 * n, st);
+        }
     }
 }
 

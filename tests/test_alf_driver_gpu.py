@@ -24,11 +24,29 @@ def smooth(rng, shape, bd):
 @pytest.mark.parametrize("bd,fmt", [(8, (1, 1)), (10, (1, 1)), (12, (1, 1)), (10, (1, 0)), (10, (0, 0))])
 @pytest.mark.parametrize("mode", ["across", "slices", "tiles", "both"])
 def test_alf_frame_pass(dev, orc, bd, fmt, mode):
+    run_alf_frame(dev, orc, bd, fmt, mode, 328, 200, 6, "random")
+
+
+# Clip indices decide which form of the filter a CTB takes (alf.hip, alf_ctb_kernel): all-zero clip indices (what the fixed filter
+# sets and APSs without non-linear clipping carry, vvc_filter.c:1147-1158) run the clamp-free dot-product form, anything else the
+# clamped one; "mixed" has one APS of each kind plus the fixed sets, "sparse" a single non-zero index in one class of one APS.
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("clips", ["zero", "mixed", "sparse"])
+@pytest.mark.parametrize("ctb_log2,w,h", [(7, 392, 280), (6, 328, 200), (5, 136, 104)])
+def test_alf_frame_pass_clip_forms(dev, orc, bd, clips, ctb_log2, w, h):
+    run_alf_frame(dev, orc, bd, (1, 1), "both" if clips == "mixed" else "across", w, h, ctb_log2, clips)
+
+
+@pytest.mark.parametrize("fmt", [(1, 0), (0, 0)])
+def test_alf_frame_pass_clip_forms_other_formats(dev, orc, fmt):
+    run_alf_frame(dev, orc, 10, fmt, "across", 392, 280, 7, "zero")
+
+
+def run_alf_frame(dev, orc, bd, fmt, mode, w, h, ctb_log2, clips):
     hs, vs = fmt                                          # 4:2:0, 4:2:2, 4:4:4
     orc.orc_alf_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.AlfFrame)]
     orc.orc_alf_frame_pass.restype = None
-    rng = np.random.default_rng(0x5EED0A00 + bd + len(mode) + 16 * hs + 32 * vs)
-    w, h, ctb_log2 = 328, 200, 6
+    rng = np.random.default_rng(0x5EED0A00 + bd + len(mode) + 16 * hs + 32 * vs + 64 * ctb_log2 + len(clips))
     ctb = 1 << ctb_log2
     cw, ch = (w + ctb - 1) // ctb, (h + ctb - 1) // ctb
     n = cw * ch
@@ -45,6 +63,18 @@ def test_alf_frame_pass(dev, orc, bd, fmt, mode):
     luma_clip = [rng.integers(0, 4, size=(25, 12)).astype(np.uint8) for _ in range(2)]
     chroma_coeff = rng.integers(-48, 48, size=(8, 6)).astype(np.int16)
     chroma_clip = rng.integers(0, 4, size=(8, 6)).astype(np.uint8)
+    if clips == "zero":
+        luma_clip = [np.zeros_like(c) for c in luma_clip]
+        chroma_clip[:] = 0
+    elif clips == "mixed":
+        luma_clip[0][:] = 0
+        chroma_clip[::2] = 0                                # every other chroma alternative is linear
+        luma_coeff[0] = rng.integers(-128, 128, size=(25, 12)).astype(np.int16)      # full coefficient range on the clamp-free form
+    elif clips == "sparse":
+        luma_clip = [np.zeros_like(c) for c in luma_clip]
+        luma_clip[1][int(rng.integers(0, 25)), int(rng.integers(0, 12))] = 3
+        chroma_clip[:] = 0
+        chroma_clip[3, 2] = 1
     cc_coeff = [rng.integers(-32, 32, size=(4, 7)).astype(np.int16) for _ in range(2)]
     aps_host = luma_coeff + luma_clip + [chroma_coeff, chroma_clip] + cc_coeff
     aps_dev = [batch.DeviceBuffer.from_host(a) for a in aps_host]
