@@ -94,28 +94,23 @@ __device__ __forceinline__ void stage_tile(uint16_t (*tile)[TW], const vvc355_al
         const int r = (int)(((uint32_t)i * recip) >> 16), k = i - r * nchunk;
         const int y = clip3(y_base + r - RA, y_min, y_max);
         const int c0 = k * 8 - kColOff;
-        const px_t *row = (const px_t *)(src + (ptrdiff_t)y * job.src_stride);
-        const uint32_t row_m = (uint32_t)__mul24(y + RA, job.src_stride);       // y >= -RA
-        uint16_t v[8];
+        const uint32_t row_m = (uint32_t)__mul24(y + RA, job.src_stride) + 8 * (int)sizeof(px_t);       // y >= -RA: byte offset of column 0
+        uint4 q;
         if (aligned && c0 >= 0 && c0 + 8 <= w) {
             if (BD > 8) {
-                const uint4 q = gld_at<uint4>(src_m, row_m + (c0 + 8) * (int)sizeof(px_t));
-                *(uint4 *)&tile[r][k * 8] = q;
-                continue;
+                q = gld_at<uint4>(src_m, row_m + c0 * (int)sizeof(px_t));
             } else {
-                const uint2 q = gld_at<uint2>(src_m, row_m + (c0 + 8) * (int)sizeof(px_t));
-                const uint32_t d[2] = { q.x, q.y };
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    v[j] = (d[j >> 2] >> ((j & 3) * 8)) & 0xff;
+                const uint2 t = gld_at<uint2>(src_m, row_m + c0);
+                q.x = __builtin_amdgcn_perm(0, t.x, 0x0c010c00u); q.y = __builtin_amdgcn_perm(0, t.x, 0x0c030c02u);
+                q.z = __builtin_amdgcn_perm(0, t.y, 0x0c010c00u); q.w = __builtin_amdgcn_perm(0, t.y, 0x0c030c02u);
             }
         } else {
+            uint32_t v[8];
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                v[j] = gld<px_t>(row + clip3(c0 + j, x_min, x_max));
+                v[j] = gld_at<px_t>(src_m, row_m + clip3(c0 + j, x_min, x_max) * (int)sizeof(px_t));
+            q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16); q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
         }
-        uint4 q;
-        q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16); q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
         *(uint4 *)&tile[r][k * 8] = q;
     }
 }
@@ -336,45 +331,51 @@ __device__ __forceinline__ uint32_t upk_ll(uint32_t a, uint32_t b) { return (a &
 __device__ __forceinline__ uint32_t pk_l0(uint32_t a) { return a & 0xffffu; }
 __device__ __forceinline__ uint32_t pk_0l(uint32_t a) { return a << 16; }
 
-// One cell of the Laplacian grid (vvc_filter_template.c:325-343): samples A = (row 1, column ca) and B = (row 2, ca + 1) of the
-// four rows the accessor px(row, column) exposes: 0 = the row above A (A's own row at the virtual boundary, :323-324), 1 = A's
-// row, 2 = B's row, 3 = the row below B (B's own row at the boundary, :321-322).  Returns V | H << 16 and D0 | D1 << 16.
-template <class F>
-__device__ __forceinline__ void grad_cell(F px, int ca, uint32_t &vh, uint32_t &dd)
+// One cell of the Laplacian grid (vvc_filter_template.c:325-343): samples A = (row 1, column ca) and B = (row 2, ca + 1) of four
+// rows given as dwords of two samples (even column in the low half): up = the row above A (A's own row at the virtual boundary,
+// :323-324), ra = A's row, rb = B's row, dn = the row below B (B's own row at the boundary, :321-322); u0 / a0 / b0 / d0 hold
+// columns ca-2 ca-1, *1 columns ca ca+1, *2 columns ca+2 ca+3.  A's term sits in the low half, B's in the high half of every
+// operand, so one v_sad_u16 per direction adds |2A - n1 - n2| + |2B - n1' - n2'|.  Returns V | H << 16 and D0 | D1 << 16.
+__device__ __forceinline__ uint32_t lo_hi(uint32_t lo_src, uint32_t hi_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060100u); }    // lo(lo_src) | hi(hi_src)
+__device__ __forceinline__ uint32_t hi_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040302u); }                       // hi(a) | lo(b) << 16
+__device__ __forceinline__ void grad_cell_pk(uint32_t u0, uint32_t u1, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2,
+                                             uint32_t d1, uint32_t d2, uint32_t &vh, uint32_t &dd)
 {
-    const int cb = ca + 1;
-    const unsigned a2 = px(1, ca) << 1, b2 = px(2, cb) << 1;
-    const unsigned v  = __sad(a2, px(0, ca) + px(2, ca), __sad(b2, px(1, cb) + px(3, cb), 0u));
-    const unsigned h  = __sad(a2, px(1, ca - 1) + px(1, ca + 1), __sad(b2, px(2, cb - 1) + px(2, cb + 1), 0u));
-    const unsigned d0 = __sad(a2, px(0, ca - 1) + px(2, ca + 1), __sad(b2, px(1, cb - 1) + px(3, cb + 1), 0u));
-    const unsigned d1 = __sad(a2, px(0, ca + 1) + px(2, ca - 1), __sad(b2, px(1, cb + 1) + px(3, cb - 1), 0u));
+    const uint32_t x2 = lo_hi(a1, b1) << 1;                                    // (2A, 2B)
+    // (neighbour of A, neighbour of B) pairs; their sums stay below 2^16, so a plain add serves both halves
+    const uint32_t v  = __builtin_amdgcn_sad_u16(x2, lo_hi(u1, a1) + lo_hi(b1, d1), 0u);        // A: up(ca) + rb(ca);        B: ra(cb) + dn(cb)
+    const uint32_t h  = __builtin_amdgcn_sad_u16(x2, hi_lo(a0, b1) + hi_lo(a1, b2), 0u);        // A: ra(ca-1) + ra(ca+1);    B: rb(cb-1) + rb(cb+1)
+    const uint32_t e0 = __builtin_amdgcn_sad_u16(x2, hi_lo(u0, a1) + hi_lo(b1, d2), 0u);        // A: up(ca-1) + rb(ca+1);    B: ra(cb-1) + dn(cb+1)
+    const uint32_t e1 = __builtin_amdgcn_sad_u16(x2, hi_lo(u1, a2) + hi_lo(b0, d1), 0u);        // A: up(ca+1) + rb(ca-1);    B: ra(cb+1) + dn(cb-1)
     vh = v | (h << 16);
-    dd = d0 | (d1 << 16);
+    dd = e0 | (e1 << 16);
 }
 
 // 7x7 diamond without clamps on one 4x4 block from the register window (KIND as in filter_block_regs).  ev[k] holds tap k's
 // coefficient in its low half.  Window column c = 4 + j of row r sits in dword c >> 1; per column parity the taps of a row pair
 // up with the dwords as they are: even c: row 0 (c-4 c-3)(c-2 c-1)(c c+1)(c+2 c+3), odd c: (c-3 c-2)(c-1 c)(c+1 c+2)(c+3 c+4), ...
 template <int BD, int KIND>
-__device__ __forceinline__ void filter_block_fast(const Win &win, const uint32_t (&ev)[12], uint8_t *drow, int dst_stride)
+__device__ __forceinline__ void filter_block_fast(const Win &win, const uint32_t (&ev)[12], int cen, uint8_t *drow, int dst_stride)
 {
-    int fsum = 0;
-#pragma unroll
-    for (int k = 0; k < 12; k++) fsum += (int)(int16_t)(ev[k] & 0xffff);
-    const int cen = -2 * fsum;                      // |cen| < 2^20: a 24-bit multiply is exact
+    // cen = -2 * sum f.  ((sum + 64) >> 7) + cur == (sum + 64 + 128 * cur) >> 7: the centre sample's weight becomes cen + 128
+    // (cen + 1024 on the rows that round with >> 10) and sits in the one free slot of the row-0 pairs; the caller has checked that
+    // both fit 16 bits.
+    const uint32_t c7 = (uint32_t)(cen + 128), c10 = (uint32_t)(cen + 1024);
     uint32_t outp[4][2];
 #pragma unroll
     for (int par = 0; par < 2; par++) {
-        uint32_t z0[4], p1[3], m1[3], p2[2], m2[2], p3;
+        uint32_t z0[4], zc7, zc10, p1[3], m1[3], p2[2], m2[2], p3;
         if (par == 0) {
-            z0[0] = pk_0l(ev[9]); z0[1] = pk_ll(ev[10], ev[11]); z0[2] = pk_0l(ev[11]); z0[3] = pk_ll(ev[10], ev[9]);
+            z0[0] = pk_0l(ev[9]); z0[1] = pk_ll(ev[10], ev[11]); z0[3] = pk_ll(ev[10], ev[9]);
+            zc7 = pk_ll(c7, ev[11]); zc10 = pk_ll(c10, ev[11]);
             p1[0] = pk_ll(ev[8], ev[7]); p1[1] = pk_ll(ev[6], ev[5]); p1[2] = pk_l0(ev[4]);
             m1[0] = pk_ll(ev[4], ev[5]); m1[1] = pk_ll(ev[6], ev[7]); m1[2] = pk_l0(ev[8]);
             p2[0] = pk_0l(ev[3]); p2[1] = pk_ll(ev[2], ev[1]);
             m2[0] = pk_0l(ev[1]); m2[1] = pk_ll(ev[2], ev[3]);
             p3 = pk_l0(ev[0]);
         } else {
-            z0[0] = pk_ll(ev[9], ev[10]); z0[1] = pk_l0(ev[11]); z0[2] = pk_ll(ev[11], ev[10]); z0[3] = pk_l0(ev[9]);
+            z0[0] = pk_ll(ev[9], ev[10]); z0[2] = pk_ll(ev[11], ev[10]); z0[3] = pk_l0(ev[9]);
+            zc7 = pk_ll(ev[11], c7); zc10 = pk_ll(ev[11], c10);
             p1[0] = pk_0l(ev[8]); p1[1] = pk_ll(ev[7], ev[6]); p1[2] = pk_ll(ev[5], ev[4]);
             m1[0] = pk_0l(ev[4]); m1[1] = pk_ll(ev[5], ev[6]); m1[2] = pk_ll(ev[7], ev[8]);
             p2[0] = pk_ll(ev[3], ev[2]); p2[1] = pk_l0(ev[1]);
@@ -385,11 +386,12 @@ __device__ __forceinline__ void filter_block_fast(const Win &win, const uint32_t
         for (int i = 0; i < 4; i++) {
             const int dist = KIND == 0 ? 3 : KIND == 1 ? 3 - i : i;
             const int r0 = 3 + i, d1 = dist < 1 ? dist : 1, d2 = dist < 2 ? dist : 2, d3 = dist < 3 ? dist : 3;
+            z0[par ? 1 : 2] = dist == 0 ? zc10 : zc7;
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
                 const int c = 4 + par + 2 * jj, m = c >> 1;
                 const int b0 = par ? m - 1 : m - 2, b2 = par ? m : m - 1;
-                int sum = 0;
+                int sum = dist == 0 ? 512 : 64;
 #pragma unroll
                 for (int q = 0; q < 4; q++) sum = sdot2(win.d[r0][b0 + q], z0[q], sum);
 #pragma unroll
@@ -404,9 +406,7 @@ __device__ __forceinline__ void filter_block_fast(const Win &win, const uint32_t
                 }
                 sum = sdot2(win.d[r0 + d3][m], p3, sum);
                 sum = sdot2(win.d[r0 - d3][m], p3, sum);
-                const int cur = win.at(r0, c);
-                sum = mad24(cen, cur, sum);
-                const int o = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+                const int o = clip_px<BD>(dist == 0 ? sum >> 10 : sum >> 7);
                 outp[i][jj] = par ? outp[i][jj] | ((uint32_t)o << 16) : (uint32_t)o;
             }
         }
@@ -443,35 +443,35 @@ __device__ __forceinline__ void chroma_quad(const uint32_t (&win)[5][4], const i
 #undef WPX
 }
 
-// the same without clamps (every clip value 2^bd, or a zero coefficient): 9 dot products + the centre per sample
+// the same without clamps (every clip value 2^bd, or a zero coefficient): 9 dot products per sample, the centre weight
+// cen = -2 * sum f and the "+ cur" in the free slot of the row-0 pairs (the caller has checked that cen + 128 / + 1024 fit 16 bits)
 template <int BD>
-__device__ __forceinline__ void chroma_quad_fast(const uint32_t (&win)[5][4], const int (&f)[6], int dist, int (&out)[4])
+__device__ __forceinline__ void chroma_quad_fast(const uint32_t (&win)[5][4], const int (&f)[6], int cen, int dist, int (&out)[4])
 {
-    const int cen = -2 * (f[0] + f[1] + f[2] + f[3] + f[4] + f[5]);
     const uint32_t F0 = f[0], F1 = f[1], F2 = f[2], F3 = f[3], F4 = f[4], F5 = f[5];
+    const uint32_t cw = (uint32_t)(cen + (dist == 0 ? 1024 : 128));
+    const uint32_t ce = upk_ll(cw, F5), co = upk_ll(F5, cw);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int c = j + 2, m = c >> 1;
-        int sum = 0;
+        int sum = dist == 0 ? 512 : 64;
         if (!(c & 1)) {                         // dwords m-1 (c-2 c-1), m (c c+1), m+1 (c+2 c+3)
-            sum = sdot2(win[2][m - 1], upk_ll(F4, F5), sum); sum = sdot2(win[2][m], pk_0l(F5), sum); sum = sdot2(win[2][m + 1], pk_l0(F4), sum);
+            sum = sdot2(win[2][m - 1], upk_ll(F4, F5), sum); sum = sdot2(win[2][m], ce, sum); sum = sdot2(win[2][m + 1], pk_l0(F4), sum);
             sum = sdot2(win[3][m - 1], pk_0l(F3), sum); sum = sdot2(win[3][m], upk_ll(F2, F1), sum);
             sum = sdot2(win[1][m - 1], pk_0l(F1), sum); sum = sdot2(win[1][m], upk_ll(F2, F3), sum);
             sum = sdot2(win[4][m], pk_l0(F0), sum); sum = sdot2(win[0][m], pk_l0(F0), sum);
         } else {                                // dwords m-1 (c-3 c-2), m (c-1 c), m+1 (c+1 c+2)
-            sum = sdot2(win[2][m - 1], pk_0l(F4), sum); sum = sdot2(win[2][m], pk_l0(F5), sum); sum = sdot2(win[2][m + 1], upk_ll(F5, F4), sum);
+            sum = sdot2(win[2][m - 1], pk_0l(F4), sum); sum = sdot2(win[2][m], co, sum); sum = sdot2(win[2][m + 1], upk_ll(F5, F4), sum);
             sum = sdot2(win[3][m], upk_ll(F3, F2), sum); sum = sdot2(win[3][m + 1], pk_l0(F1), sum);
             sum = sdot2(win[1][m], upk_ll(F1, F2), sum); sum = sdot2(win[1][m + 1], pk_l0(F3), sum);
             sum = sdot2(win[4][m], pk_0l(F0), sum); sum = sdot2(win[0][m], pk_0l(F0), sum);
         }
-        const int cur = (int)((win[2][m] >> ((c & 1) * 16)) & 0xffff);
-        sum = mad24(cen, cur, sum);
-        out[j] = clip_px<BD>((dist == 0 ? (sum + 512) >> 10 : (sum + 64) >> 7) + cur);
+        out[j] = clip_px<BD>(dist == 0 ? sum >> 10 : sum >> 7);
     }
 }
 
 template <int BD, bool CHROMA>
-__global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__restrict__ luma_jobs, const vvc355_alf_job *__restrict__ chroma_jobs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void alf_ctb_kernel(const vvc355_alf_job *__restrict__ luma_jobs, const vvc355_alf_job *__restrict__ chroma_jobs,
                                                       const vvc355_alf_job *__restrict__ cc_jobs, int log2_strips)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileH][kTileW];
@@ -534,13 +534,10 @@ __global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__re
                 up[m] = fold_up ? win.d[ra][m] : win.d[ra - 1][m];
                 dn[m] = fold_dn ? win.d[ra + 1][m] : win.d[ra + 2][m];
             }
-            auto px = [&](int r, int c) -> unsigned {
-                const uint32_t v = r == 0 ? up[c >> 1] : r == 1 ? win.d[ra][c >> 1] : r == 2 ? win.d[ra + 1][c >> 1] : dn[c >> 1];
-                return (v >> ((c & 1) * 16)) & 0xffffu;
-            };
+            const uint32_t *A = win.d[ra], *B = win.d[ra + 1];
             uint4 e;
-            grad_cell(px, 4, e.x, e.y);
-            grad_cell(px, 6, e.z, e.w);
+            grad_cell_pk(up[1], up[2], A[1], A[2], A[3], B[1], B[2], B[3], dn[2], dn[3], e.x, e.y);      // A on window column 4
+            grad_cell_pk(up[2], up[3], A[2], A[3], A[4], B[2], B[3], B[4], dn[3], dn[4], e.z, e.w);      // A on window column 6
             cells[2 * by + 1 + q][bx + 1] = e;
         }
     }
@@ -556,10 +553,16 @@ __global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__re
             else                   { cr = e - 67 - ncr; bc = nbx; }
             const int ya = y_base - 2 + 2 * cr, ta = 2 * cr + 1;
             const int rsel[4] = { ya == vb_pos ? ta : ta - 1, ta, ta + 1, ya == vb_pos - 2 ? ta + 1 : ta + 2 };
-            auto px = [&](int r, int c) -> unsigned { return tile[rsel[r]][c]; };
+            uint32_t R[4][4];                       // columns 4 bc - 2 .. 4 bc + 5 of the four rows
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t *p = (const uint32_t *)&tile[rsel[r]][4 * bc + kColOff - 2];
+#pragma unroll
+                for (int m = 0; m < 4; m++) R[r][m] = p[m];
+            }
             uint4 v;
-            grad_cell(px, 4 * bc + kColOff, v.x, v.y);
-            grad_cell(px, 4 * bc + kColOff + 2, v.z, v.w);
+            grad_cell_pk(R[0][0], R[0][1], R[1][0], R[1][1], R[1][2], R[2][0], R[2][1], R[2][2], R[3][1], R[3][2], v.x, v.y);
+            grad_cell_pk(R[0][1], R[0][2], R[1][1], R[1][2], R[1][3], R[2][1], R[2][2], R[2][3], R[3][2], R[3][3], v.z, v.w);
             cells[cr][bc + 1] = v;
         }
     }
@@ -609,10 +612,15 @@ __global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__re
         // rows of this block closer than 3 to the virtual boundary fold their taps
         const bool near_vb = vb_dist(yb, vb_pos) < 3 || vb_dist(yb + 3, vb_pos) < 3 || (yb < vb_pos && yb + 3 >= vb_pos);
         const int kind = !near_vb ? 0 : yb + 4 == vb_pos ? 1 : yb == vb_pos ? 2 : 3;
-        if (noclip && kind < 3) {
-            if (kind == 0)      filter_block_fast<BD, 0>(win, ev, drow, job.dst_stride);
-            else if (kind == 1) filter_block_fast<BD, 1>(win, ev, drow, job.dst_stride);
-            else                filter_block_fast<BD, 2>(win, ev, drow, job.dst_stride);
+        int cen = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) cen += (int)(int16_t)(ev[k] & 0xffff);
+        cen *= -2;
+        // the clamp-free form carries the centre weight as a 16-bit operand (always true for coefficients in the standard's range)
+        if (noclip && kind < 3 && cen >= -32768 && cen + 1024 <= 32767) {
+            if (kind == 0)      filter_block_fast<BD, 0>(win, ev, cen, drow, job.dst_stride);
+            else if (kind == 1) filter_block_fast<BD, 1>(win, ev, cen, drow, job.dst_stride);
+            else                filter_block_fast<BD, 2>(win, ev, cen, drow, job.dst_stride);
         } else {
             // clamped form, any boundary position: one block row at a time from the tile, tap rows folded onto the virtual boundary
             // when they are fetched (:80-96), so one body serves every row
@@ -701,8 +709,9 @@ __global__ __launch_bounds__(256) void alf_ctb_kernel(const vvc355_alf_job *__re
                 }
             }
             int out[4];
-            if (cclamps) chroma_quad<BD>(w5, f, cl, dist, out);
-            else         chroma_quad_fast<BD>(w5, f, dist, out);
+            const int ccen = -2 * (f[0] + f[1] + f[2] + f[3] + f[4] + f[5]);
+            if (cclamps || ccen < -32768 || ccen + 1024 > 32767) chroma_quad<BD>(w5, f, cl, dist, out);
+            else                                                 chroma_quad_fast<BD>(w5, f, ccen, dist, out);
             if (P.cc_on) {
                 int g[7];
 #pragma unroll
@@ -912,15 +921,17 @@ __global__ void alf_recon_kernel(int16_t *coeff, int16_t *clip, const int *class
 // CC-ALF jobs that are switched off (w = h = 0).
 __device__ static const int16_t kAlfZeroSet[25 * 12] = { 0 };
 
-// ff_vvc_alf_filter (vvc_filter.c:1254-1318) per CTB as a descriptor builder: one lane per CTB writes its luma job, two chroma
-// jobs and two CC-ALF jobs.  edges[] (:1264-1278) become ext_* = 0 (replicate) / 3 (read the neighbour in place).
+// ff_vvc_alf_filter (vvc_filter.c:1254-1318) per CTB as a descriptor builder: three lanes per CTB write its luma job, and per
+// chroma component the chroma job, the CC-ALF job and the CTB kernel's parameter block.  edges[] (:1264-1278) become ext_* = 0 (replicate) / 3 (read the neighbour in place).
 template <int BD>
 __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int n_ctbs, vvc355_alf_job *luma, vvc355_alf_job *chroma,
                                  vvc355_alf_job *cc, AlfChromaParams *params)
 {
     const vvc355_alf_frame F = load_uniform(frame);       // scalar loads, once: the fields are read dozens of times
     const vvc355_alf_frame *fp = &F;
-    const int rs = blockIdx.x * blockDim.x + threadIdx.x;
+    // three lanes per CTB (luma job; Cb jobs; Cr jobs): the chain of dependent table reads per lane is a third as long
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rs = t / 3, comp = t - rs * 3;
     if (rs >= n_ctbs)
         return;
     const int px = BD > 8 ? 2 : 1;
@@ -947,7 +958,7 @@ __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int
     vvc355_alf_job j = {};
     j.ext_l = e_l ? 0 : 3; j.ext_t = e_t ? 0 : 3; j.ext_r = e_r ? 0 : 3; j.ext_b = e_b ? 0 : 3;
     // ---- luma: alf_filter_luma (:1171) with alf_get_coeff_and_clip (:1142)
-    {
+    if (comp == 0) {
         const int x0 = xc * ctb_size, y0 = yc * ctb_size;
         j.dst = fp->dst[0] + (uint64_t)y0 * fp->dst_stride[0] + x0 * px;
         j.src = fp->src[0] + (uint64_t)y0 * fp->src_stride[0] + x0 * px;
@@ -964,13 +975,15 @@ __global__ void alf_build_kernel(const vvc355_alf_frame *__restrict__ frame, int
             j.class_to_filt = (uint64_t)t_alf_aps_class_to_filt_map;
         }
         luma[rs] = j;
+        return;
     }
     if (fp->n_comp < 3)
         return;
     const int hs = fp->hs, vs = fp->vs;
     const int x0 = (xc * ctb_size) >> hs, y0 = (yc * ctb_size) >> vs;
     const int w = min((fp->width >> hs) - x0, ctb_size >> hs), h = min((fp->height >> vs) - y0, ctb_size >> vs);
-    for (int c = 1; c < 3; c++) {
+    {
+        const int c = comp;
         // ---- chroma: alf_filter_chroma (:1195)
         j.dst = fp->dst[c] + (uint64_t)y0 * fp->dst_stride[c] + x0 * px;
         j.src = fp->src[c] + (uint64_t)y0 * fp->src_stride[c] + x0 * px;
@@ -1105,7 +1118,7 @@ void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_d
     vvc355_alf_job *luma = (vvc355_alf_job *)work_dev, *chroma = luma + n, *cc = chroma + 2 * n;
     AlfChromaParams *params = (AlfChromaParams *)(cc + 2 * n);
     hipStream_t st = (hipStream_t)stream;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, params));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((3 * n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, params));
     HIP_CHECK(hipGetLastError());
     const int ctb_size = 1 << frame_host->ctb_log2;
     if (frame_host->n_comp >= 3 && frame_host->hs == 1 && frame_host->vs == 1) {

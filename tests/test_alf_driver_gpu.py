@@ -75,6 +75,10 @@ def run_alf_frame(dev, orc, bd, fmt, mode, w, h, ctb_log2, clips):
         luma_clip[1][int(rng.integers(0, 25)), int(rng.integers(0, 12))] = 3
         chroma_clip[:] = 0
         chroma_clip[3, 2] = 1
+        # coefficients far outside the standard's range in a few classes / alternatives: the centre weight -2 * sum(f) no longer fits
+        # the 16-bit operand of the clamp-free form, those blocks must take the clamped form (same result, int32 arithmetic)
+        luma_coeff[0][::6] = rng.integers(-3000, 3000, size=luma_coeff[0][::6].shape)
+        chroma_coeff[5] = rng.integers(-6000, -3000, size=6)
     cc_coeff = [rng.integers(-32, 32, size=(4, 7)).astype(np.int16) for _ in range(2)]
     aps_host = luma_coeff + luma_clip + [chroma_coeff, chroma_clip] + cc_coeff
     aps_dev = [batch.DeviceBuffer.from_host(a) for a in aps_host]
