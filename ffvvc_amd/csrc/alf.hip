@@ -26,18 +26,30 @@ static constexpr int kColOff  = 8;
 #include "tables.inc"
 #undef VVC355_TABLE
 
-__device__ static const uint8_t kAlfPerm[4][12] = {       // vvc_filter_template.c:387-392
-    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 },
-    { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6 },
-    { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11 },
-    { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6 },
-};
-__device__ static const uint8_t kAlfVarTab[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+// alf_recon_coeff_and_clip's transpose index lists (vvc_filter_template.c:387-392) and alf_get_idx's arg_var (:272): generated from the
+// reference's initialisers (tables_small.inc; tables.cpp exports the same text for the table check), once as device arrays and once
+// as compile-time constants for the packed forms below
+#define VVC355_TABLE(type, name, count) __device__ static const type t_##name[count]
+#include "tables_small.inc"
+#undef VVC355_TABLE
+#define VVC355_TABLE(type, name, count) static constexpr type c_##name[count]
+#include "tables_small.inc"
+#undef VVC355_TABLE
+#define kAlfVarTab t_alf_arg_var
 // luma diamond taps (dy, dx), paired with (-dy, -dx): vvc_filter_template.c:102-113
 __device__ static constexpr int8_t kLumaTap[12][2] = {
     { 3, 0 }, { 2, 1 }, { 2, 0 }, { 2, -1 }, { 1, 2 }, { 1, 1 }, { 1, 0 }, { 1, -1 }, { 1, -2 }, { 0, 3 }, { 0, 2 }, { 0, 1 },
 };
 // chroma 5x5 diamond taps (dy, dx), each paired with its mirror: (2,0) (1,1) (1,0) (1,-1) (0,2) (0,1) — unrolled in alf_chroma_kernel
+
+// taps first .. first + 7 of transpose t's index list, one 4-bit field per tap
+constexpr uint32_t alf_perm_nibbles(int t, int first)
+{
+    uint32_t v = 0;
+    for (int k = first; k < 12 && k < first + 8; k++)
+        v |= (uint32_t)c_alf_transpose_index[t * 12 + k] << (4 * (k - first));
+    return v;
+}
 
 // clamp(x, -c, c) in one VALU op (the compiler cannot prove -c <= c, so it would emit max + min)
 __device__ __forceinline__ int clamp_sym(int x, int c)
@@ -598,7 +610,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         // permutations as 4-bit fields (taps 0..7 | taps 8..11)
         uint32_t ev[12];
         {
-            constexpr uint32_t PL[4] = { 0x76543210u, 0x7b518a49u, 0x56781230u, 0x5b734a89u }, PH[4] = { 0xba98u, 0x6203u, 0xba94u, 0x6201u };
+            constexpr uint32_t PL[4] = { alf_perm_nibbles(0, 0), alf_perm_nibbles(1, 0), alf_perm_nibbles(2, 0), alf_perm_nibbles(3, 0) };
+            constexpr uint32_t PH[4] = { alf_perm_nibbles(0, 8), alf_perm_nibbles(1, 8), alf_perm_nibbles(2, 8), alf_perm_nibbles(3, 8) };
             const uint32_t pl = tr == 0 ? PL[0] : tr == 1 ? PL[1] : tr == 2 ? PL[2] : PL[3];
             const uint32_t ph = tr == 0 ? PH[0] : tr == 1 ? PH[1] : tr == 2 ? PH[2] : PH[3];
             const uint32_t *row = &ftab[cls * 12];
@@ -909,7 +922,7 @@ __global__ void alf_recon_kernel(int16_t *coeff, int16_t *clip, const int *class
     if (i >= size * 12)
         return;
     const int b = i / 12, j = i - b * 12;
-    const int cls = class_idx[b], idx = kAlfPerm[transpose_idx[b]][j];
+    const int cls = class_idx[b], idx = t_alf_transpose_index[transpose_idx[b] * 12 + j];
     const int q = clip_idx_set[cls * 12 + idx];
     coeff[i] = coeff_set[class_to_filt[cls] * 12 + idx];
     clip[i] = (int16_t)(1 << (BD - (q == 0 ? 0 : 2 * q + 1)));

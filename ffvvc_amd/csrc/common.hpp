@@ -10,8 +10,9 @@
 
 // DSP slots return void and cannot report failure (vvcdsp.h:48-158): by default a HIP error is fatal and loud.  A host that drives the
 // batched / frame entries itself can ask for errors to be recorded instead (vvc355_set_error_policy(1)): the first failure is kept
-// (vvc355_last_error / _string), the entry goes on (HIP errors are sticky, later calls fail too) and the host checks after the
-// stage or at its stream synchronisation.
+// (vvc355_last_error / _string, text written before the code is published), the entry goes on — launch and copy errors are sticky,
+// later calls fail too; a thread whose stream / staging arena could not be created aborts at its first slot call — and the host
+// checks after the stage or at its stream synchronisation.
 namespace vvc355 { void hip_fail(const char *expr, int err, const char *what, const char *file, int line); }
 #define HIP_CHECK(expr)                                                                         \
     do {                                                                                        \

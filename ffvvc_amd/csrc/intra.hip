@@ -40,7 +40,13 @@ static constexpr int kEdgeLen = 6 * 64 + 5;
 // intraPredAngle and invAngle = round(16384 / intraPredAngle) of a directional mode, one packed table entry (angle | inv << 16).
 // The reference rounds a float quotient (vvc_intra.c:683-690); no quotient of the 30 table angles is within float error of a half,
 // so the integer form is exact (tests/test_oracle_cpu.py checks all of them).
-__host__ __device__ inline uint32_t intra_angle_entry(int aidx)
+// the reference's inline tables as compile-time constants (tables_small.inc, generated from its initialisers; tables.cpp exports the
+// same text for the table check): the packed / arithmetic forms below are proven equal to them by static_assert
+#define VVC355_TABLE(type, name, count) static constexpr type c_##name[count]
+#include "tables_small.inc"
+#undef VVC355_TABLE
+
+__host__ __device__ constexpr uint32_t intra_angle_entry(int aidx)
 {
 #define VVC355_AI(a) ((uint32_t)(a) | (uint32_t)((16384 + (a) / 2) / (a)) << 16)
     const uint32_t tab[32] = { 0, VVC355_AI(1), VVC355_AI(2), VVC355_AI(3), VVC355_AI(4), VVC355_AI(6), VVC355_AI(8), VVC355_AI(10), VVC355_AI(12),
@@ -50,6 +56,14 @@ __host__ __device__ inline uint32_t intra_angle_entry(int aidx)
 #undef VVC355_AI
     return tab[aidx];
 }
+constexpr bool intra_angles_match()
+{
+    for (int i = 0; i < 31; i++)
+        if ((int)(intra_angle_entry(i) & 0xffff) != c_intra_angles[i])
+            return false;
+    return true;
+}
+static_assert(intra_angles_match(), "intra_angle_entry() != angles[] of ff_vvc_intra_pred_angle_derive (vvc_intra.c:667-670)");
 __host__ __device__ inline int intra_angle_index(int mode) { return mode > 34 ? mode - 50 : mode > 0 ? 18 - mode : 16 - mode; }
 __host__ __device__ inline void intra_angle_split(int idx, uint32_t e, int *angle, int *inv)
 {
@@ -91,13 +105,34 @@ __host__ __device__ inline int intra_need_pdpc(int w, int h, int bdpcm_flag, int
     return 0;
 }
 // the modes whose reference samples get the [1 2 1] filter (:450): -14 -12 -10 -6 0 2 34 66 72 76 78 80, as a bit test on mode + 14
-__host__ __device__ inline bool ref_filter_mode(int mode)
+__host__ __device__ constexpr bool ref_filter_mode(int mode)
 {
     const unsigned m = (unsigned)(mode + 14);
     const unsigned long long lo = (1ull << 0) | (1ull << 2) | (1ull << 4) | (1ull << 8) | (1ull << 14) | (1ull << 16) | (1ull << 48);
     const unsigned long long hi = (1ull << (80 - 64)) | (1ull << (86 - 64)) | (1ull << (90 - 64)) | (1ull << (92 - 64)) | (1ull << (94 - 64));
     return m < 64 ? (lo >> m) & 1 : m < 95 ? (hi >> (m - 64)) & 1 : false;
 }
+constexpr bool ref_filter_modes_match()
+{
+    for (int mode = -14; mode <= 80; mode++) {
+        bool listed = false;
+        for (int k = 0; k < 12; k++) listed = listed || c_ref_filter_modes[k] == mode;
+        if (ref_filter_mode(mode) != listed)
+            return false;
+    }
+    return true;
+}
+static_assert(ref_filter_modes_match(), "ref_filter_mode() != modes[] of ff_vvc_ref_filter_flag_derive (vvc_intra.c:657)");
+// distance threshold of the 4-tap filter choice (intra_hor_ver_dist_thres, vvc_intra_template.c:559) and CCLM's divSigTable (:261)
+__host__ __device__ constexpr int intra_filter_thres(int ti) { return ti == 0 ? 24 : ti == 1 ? 14 : ti == 2 ? 2 : 0; }
+__host__ __device__ constexpr int cclm_div_sig(int norm) { return (int)((0x0111122334455670ull >> (4 * norm)) & 15); }
+constexpr bool intra_small_tables_match()
+{
+    for (int i = 0; i < 5; i++) if (intra_filter_thres(i) != c_intra_filter_thres[i]) return false;
+    for (int i = 0; i < 16; i++) if (cclm_div_sig(i) != c_cclm_div_sig[i]) return false;
+    return true;
+}
+static_assert(intra_small_tables_match(), "filter thresholds / div_sig differ from vvc_intra_template.c:559,:261");
 
 // reference-sample accessors: pixel-typed global arrays (leaf slots) or uint16 LDS arrays (flattened intra_pred)
 template <int BD> struct GRef {
@@ -639,7 +674,7 @@ __device__ void intra_pred_body(const vvc355_intra_job &j, PX plane, int stride_
         if (!(rff || ref_idx || !no_isp)) {
             const int ti = max(0, ((ilog2i(w) + ilog2i(h)) >> 1) - 2);           // thresholds 24, 14, 2, 0, 0
             const int dist = min(abs(mode - 50), abs(mode - 18));
-            filter_flag = dist > (ti == 0 ? 24 : ti == 1 ? 14 : ti == 2 ? 2 : 0);
+            filter_flag = dist > intra_filter_thres(ti);
         }
         if (mode >= 34) {
             if (angle < 0) {
@@ -844,7 +879,15 @@ void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
     const int y1 = job->y + reach_y < job->plane_h ? job->y + reach_y : job->plane_h;
     SlotCall call;
     uint8_t *org = (uint8_t *)(uintptr_t)job->plane + (ptrdiff_t)y0 * job->stride + (ptrdiff_t)x0 * px;
-    const Staged s = call.rect(org, job->stride, 0, (ptrdiff_t)(x1 - x0) * px, 0, y1 - y0, true, true);
+    // the window (reference lines, the coding unit's other ISP partitions) is read only; what comes back is the predicted w x h block:
+    // RECON of a CTU runs beside INTER of the CTU to its right (vvc_thread.c:156-184), whose samples may lie in the window
+    const Staged s = call.rect(org, job->stride, 0, (ptrdiff_t)(x1 - x0) * px, 0, y1 - y0, true, false);
+    // (DC and horizontal blocks are written in groups of four samples like the reference's, vvc_intra_template.c:858,884: a 2-wide
+    // chroma block's footprint is 4 wide)
+    int fw = (!job->is_mip && (job->mode == 1 || job->mode == 18)) ? (job->w + 3) & ~3 : job->w;
+    if (job->x + fw > x1) fw = x1 - job->x;
+    call.download(org + (ptrdiff_t)(job->y - y0) * job->stride + (ptrdiff_t)(job->x - x0) * px, job->stride,
+                  s.dev + (ptrdiff_t)(job->y - y0) * s.pitch + (ptrdiff_t)(job->x - x0) * px, s.pitch, (size_t)fw * px, job->h);
     vvc355_intra_job dj = *job;
     dj.plane = (uint64_t)(s.dev - (ptrdiff_t)y0 * s.pitch - (ptrdiff_t)x0 * px);
     dj.stride = (int32_t)s.pitch;
@@ -1008,7 +1051,7 @@ __device__ void cclm_body(const vvc355_cclm_job &j, PX luma, int ls, PX cb, PX c
                 const int norm = ((diff << 4) >> xl) & 15;
                 xl += norm ? 1 : 0;
                 const int yl = abs(diffc) > 0 ? ilog2(abs(diffc)) + 1 : 0;
-                const int v = (int)((0x0111122334455670ull >> (4 * norm)) & 15) | 8;
+                const int v = cclm_div_sig(norm) | 8;
                 a[i2] = (diffc * v + ((1 << yl) >> 1)) >> yl;
                 k[i2] = max(1, 3 + xl - yl);
                 if (3 + xl - yl < 1)
@@ -1158,11 +1201,19 @@ void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, 
                                job->luma_stride, 0, (ptrdiff_t)(lx1 - lx0) * px, 0, ly1 - ly0, true, false);
     dj.luma = (uint64_t)(l.dev - (ptrdiff_t)ly0 * l.pitch - (ptrdiff_t)lx0 * px); dj.luma_stride = (int32_t)l.pitch;
     const Staged b = call.rect((uint8_t *)(uintptr_t)job->cb + (ptrdiff_t)cy0 * job->cb_stride + (ptrdiff_t)cx0 * px,
-                               job->cb_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, true);
+                               job->cb_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, false);
     dj.cb = (uint64_t)(b.dev - (ptrdiff_t)cy0 * b.pitch - (ptrdiff_t)cx0 * px); dj.cb_stride = (int32_t)b.pitch;
     const Staged r = call.rect((uint8_t *)(uintptr_t)job->cr + (ptrdiff_t)cy0 * job->cr_stride + (ptrdiff_t)cx0 * px,
-                               job->cr_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, true);
+                               job->cr_stride, 0, (ptrdiff_t)(cx1 - cx0) * px, 0, cy1 - cy0, true, false);
     dj.cr = (uint64_t)(r.dev - (ptrdiff_t)cy0 * r.pitch - (ptrdiff_t)cx0 * px); dj.cr_stride = (int32_t)r.pitch;
+    // only the predicted chroma blocks come back (the windows hold neighbours that other decoder threads may be writing)
+    {
+        const int bx = job->x0 >> hs, by = job->y0 >> vs, bw = job->width >> hs, bh = job->height >> vs;
+        call.download((uint8_t *)(uintptr_t)job->cb + (ptrdiff_t)by * job->cb_stride + (ptrdiff_t)bx * px, job->cb_stride,
+                      b.dev + (ptrdiff_t)(by - cy0) * b.pitch + (ptrdiff_t)(bx - cx0) * px, b.pitch, (size_t)bw * px, bh);
+        call.download((uint8_t *)(uintptr_t)job->cr + (ptrdiff_t)by * job->cr_stride + (ptrdiff_t)bx * px, job->cr_stride,
+                      r.dev + (ptrdiff_t)(by - cy0) * r.pitch + (ptrdiff_t)(bx - cx0) * px, r.pitch, (size_t)bw * px, bh);
+    }
     vvc355_cclm_batch(call.stream(), bd, call.upload(&dj, 1), 1);
 }
 
@@ -1699,14 +1750,26 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                 }
                 dst.st4(o, d[0], d[1], d[2], d[3]);
             };
+            if (w < 4) {
+                // the 1- and 2-sample-wide transform blocks of a vertically split ISP coding unit (get_luma_predict_unit, vvc_intra.c:216-226:
+                // predicted 4 wide, residuals added per sub-partition): one sample per lane and step, any column parity
+                for (int i = tid; i < n; i += 64) {
+                    const int o = (i >> lw) * stride + (i & (w - 1));
+                    int r = gld<int>(res + i);
+                    if (c.joint & 1)
+                        r = (r * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
+                    dst.st(o, clip_px<BD>(dst.ld(o) + r));
+                }
+            } else {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = tid * 4 + 256 * u;
-                if (i < n)
-                    add4(i, have ? pre[u] : gld<int4>(res + i));
+                for (int u = 0; u < 4; u++) {
+                    const int i = tid * 4 + 256 * u;
+                    if (i < n)
+                        add4(i, have ? pre[u] : gld<int4>(res + i));
+                }
+                for (int i = tid * 4 + 1024; i < n; i += 256)
+                    add4(i, gld<int4>(res + i));
             }
-            for (int i = tid * 4 + 1024; i < n; i += 256)
-                add4(i, gld<int4>(res + i));
             if (TILE) group_sync<64>(); else recon_sync_mem();
         }
         RPROF_ADD(9 + (int)c.kind + 32 * role, t_cmd);

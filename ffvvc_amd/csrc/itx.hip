@@ -16,6 +16,29 @@ namespace vvc355 {
 #define VVC355_TABLE(type, name, count) __device__ static const type d_tab_##name[count]
 #include "tables.inc"
 #undef VVC355_TABLE
+// the reference's inline tables as compile-time constants (tables_small.inc): the arithmetic / packed forms the kernels use are proven
+// equal to them here
+#define VVC355_TABLE(type, name, count) static constexpr type c_##name[count]
+#include "tables_small.inc"
+#undef VVC355_TABLE
+// levelScale[rect_non_ts][qp % 6] of the scaling process (level_scale, vvc_intra.c:329-336)
+__host__ __device__ constexpr int level_scale_of(int rect, int rem)
+{
+    return rect ? (rem == 0 ? 57 : rem == 1 ? 64 : rem == 2 ? 72 : rem == 3 ? 80 : rem == 4 ? 90 : 102)
+                : (rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72);
+}
+// 6.5.2 up-right diagonal scan of a 4x4 block (ff_vvc_diag_scan_x / _y [2][2], vvc_data.c:27,152), one 4-bit field per scan position
+static constexpr unsigned long long kDiag4X = 0x3323213210210100ull, kDiag4Y = 0x3231230123012010ull;
+constexpr bool itx_small_tables_match()
+{
+    for (int r = 0; r < 2; r++)
+        for (int q = 0; q < 6; q++)
+            if (level_scale_of(r, q) != c_level_scale[r * 6 + q]) return false;
+    for (int i = 0; i < 16; i++)
+        if ((int)((kDiag4X >> (4 * i)) & 15) != c_diag_scan_4x4_x[i] || (int)((kDiag4Y >> (4 * i)) & 15) != c_diag_scan_4x4_y[i]) return false;
+    return true;
+}
+static_assert(itx_small_tables_match(), "level scale / 4x4 diagonal scan differ from vvc_intra.c:329-336 / vvc_data.c:27,152");
 
 enum { TX_DCT2 = 0, TX_DST7 = 1, TX_DCT8 = 2 };
 
@@ -106,10 +129,7 @@ struct Dequant {
         bd_shift = ts ? 10 : bit_depth + rect + (log_sum / 2) + 10 - range + dep_quant;
         bd_offset = (1 << bd_shift) >> 1;
         const int qp = qp_in + (dep_quant && !ts ? 1 : 0), rem = qp % 6;
-        // levelScale[rect][rem]: { 40, 45, 51, 57, 64, 72 } / { 57, 64, 72, 80, 90, 102 }
-        const int lsv = rect ? (rem == 0 ? 57 : rem == 1 ? 64 : rem == 2 ? 72 : rem == 3 ? 80 : rem == 4 ? 90 : 102)
-                             : (rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72);
-        scale = lsv << (qp / 6);
+        scale = level_scale_of(rect, rem) << (qp / 6);
     }
     __device__ __forceinline__ int apply(int c, int x, int y) const
     {
@@ -750,7 +770,7 @@ __global__ __launch_bounds__(256) void lfnst_batch_kernel(const vvc355_lfnst_job
     const int n_out = big ? 48 : 16;
     const int nz = ((w == 8 && h == 8) || (w == 4 && h == 4)) ? 8 : 16;
     // 6.5.2 up-right diagonal scan of a 4x4 block (ff_vvc_diag_scan_x / _y [2][2]), packed one nibble per position
-    const unsigned long long sx = 0x3323213210210100ull, sy = 0x3231230123012010ull;
+    const unsigned long long sx = kDiag4X, sy = kDiag4Y;
     if (lane < 16)
         u_all[wave][lane] = lane < nz ? gld<int>(coeffs + w * (int)((sy >> (4 * lane)) & 15) + (int)((sx >> (4 * lane)) & 15)) : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -769,16 +769,13 @@ __global__ __launch_bounds__(256) void deblock_kernel(const vvc355_deblock_job *
                                gld<uint8_t>(&jp->max_len_q[seg]));
 }
 
-// Table 43 (beta', tc' from Q), vvc_filter.c:38-52
-__device__ static const uint16_t kTcTable[66] = {
-    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10,
-    10, 11, 13, 14, 15, 17, 19, 21, 24, 25, 29, 33, 36, 41, 45, 51, 57, 64, 71, 80, 89, 100, 112, 125, 141, 157, 177, 198, 222, 250, 280, 314,
-    352, 395,
-};
-__device__ static const uint8_t kBetaTable[64] = {
-    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
-    26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64, 66, 68, 70, 72, 74, 76, 78, 80, 82, 84, 86, 88,
-};
+// Table 43 (beta', tc' from Q), vvc_filter.c:38-52: generated from the reference's initialisers (tables_small.inc), the same text
+// tables.cpp exports as vvc355_tab_tc_table / _beta_table for the table check
+#define VVC355_TABLE(type, name, count) __device__ static const type lf_tab_##name[count]
+#include "tables_small.inc"
+#undef VVC355_TABLE
+#define kTcTable lf_tab_tc_table
+#define kBetaTable lf_tab_beta_table
 
 // One deblocking pass of a picture straight from the decoder's side tables (ff_vvc_deblock_vertical / _horizontal,
 // vvc_filter.c:864-1003, per-CTU loop flattened): two lanes per 8-sample unit of an edge, as in deblock_kernel, but each lane

@@ -1,4 +1,5 @@
 #include "runtime.hpp"
+#include <mutex>
 
 namespace vvc355 {
 
@@ -20,9 +21,13 @@ void hip_fail(const char *expr, int err, const char *what, const char *file, int
     fprintf(stderr, "vvc_mi355: %s failed: %s (%s:%d)\n", expr, what, file, line);
     if (g_error_policy.load() == 0)
         abort();
-    int none = 0;
-    if (g_last_error.compare_exchange_strong(none, err))
+    // the first failure is kept: the text is complete before the code becomes visible to vvc355_last_error()
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (g_last_error.load() == 0) {
         snprintf(g_last_error_text, sizeof(g_last_error_text), "%s failed: %s (%s:%d)", expr, what, file, line);
+        g_last_error.store(err ? err : -1);
+    }
 }
 
 ThreadCtx::ThreadCtx()
@@ -65,6 +70,11 @@ SlotCall::~SlotCall()
 uint8_t *SlotCall::bump(size_t bytes)
 {
     const size_t at = (used_ + 255) & ~(size_t)255;
+    if (!ctx_.dev || !ctx_.stream) {
+        // under error policy 1 a failed stream / arena creation was only recorded; a slot call cannot go on without them
+        fprintf(stderr, "vvc_mi355: this thread has no staging arena (its creation failed: %s)\n", last_error_text());
+        abort();
+    }
     if (at + bytes > ctx_.cap) {
         fprintf(stderr, "vvc_mi355: slot staging arena exhausted (%zu + %zu > %zu)\n", at, bytes, ctx_.cap);
         abort();

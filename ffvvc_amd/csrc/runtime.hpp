@@ -41,6 +41,12 @@ public:
     // upload: copy host -> device now; download: copy device -> host when the call object is destroyed.
     Staged rect(const void *host, ptrdiff_t stride, ptrdiff_t x_lo, ptrdiff_t x_hi, int y_lo, int y_hi,
                 bool upload, bool download);
+    // copy back only `rows` rows of `width` bytes at `host` (whose staged twin is `dev`) when the call object is destroyed: for slots
+    // that read a window but own only a part of it (other decoder threads may be writing the rest of the window meanwhile)
+    void download(void *host, ptrdiff_t hstride, uint8_t *dev, ptrdiff_t dpitch, size_t width, int rows)
+    {
+        if (width && rows > 0) outs_.push_back({ host, hstride, dev, dpitch, width, rows });
+    }
     // linear byte range [0, bytes)
     void *linear(const void *host, size_t bytes, bool upload, bool download);
     void *scratch(size_t bytes);

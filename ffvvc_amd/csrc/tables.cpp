@@ -4,3 +4,6 @@
 #include <stdint.h>
 #define VVC355_TABLE(type, name, count) extern "C" __attribute__((visibility("default"))) const type vvc355_tab_##name[count]
 #include "tables.inc"
+// the small tables the reference keeps inline in its .c files (tools/gen_tables.py, main_small): the kernels use these same initialisers
+// directly (loopfilter.hip, alf.hip) or prove their packed forms equal to them at compile time (intra.hip, itx.hip, alf.hip)
+#include "tables_small.inc"

@@ -2,10 +2,10 @@
  * vvc_mi355_ctx.h — the decoder state the four context-taking slots read, as a plain-C mirror.
  *
  * intra.intra_pred, intra.intra_cclm_pred, intra.lmcs_scale_chroma (libavcodec/vvc/vvcdsp.h:98-100) take the decoder's
- * VVCLocalContext, sao.edge_restore[2] (:143) its SAOParams.  Inside an FFmpeg tree ffvvc_amd/host/dsp_ctx_shim.c is compiled
- * against the decoder's own headers (INTEGRATION.md section 2 lists the field-for-field mapping); this header gives the
- * standalone build the same names with exactly the fields those slots read, so that the flattening code — including the
- * availability process over the running list of reconstructed areas — is compiled and tested here.
+ * VVCLocalContext, sao.edge_restore[2] (:143) its SAOParams.  ffvvc_amd/host/dsp_ctx_shim.c reads every member through accessor
+ * macros; this header gives the standalone build (the one compiled and tested here) the same struct names with exactly the
+ * members those slots read.  The accessors' VVC355_IN_TREE branch maps them onto the decoder's own headers (INTEGRATION.md
+ * section 2); that branch needs FFmpeg's configure output and is not compiled in this repository.
  * Field names follow the reference (vvc_ctu.h:334-460, vvc_ps.h:193-202, vvcdec.h:122-187); nothing else of those structs exists.
  */
 #ifndef VVC_MI355_CTX_H
@@ -71,9 +71,12 @@ typedef struct VVCLocalContext {                    /* vvc_ctu.h:354-436: the me
 /* the flattening itself, exposed for the CPU tests: fills the job a slot call turns into (no GPU work) */
 void vvc355_ctx_flatten_intra_pred(const VVCLocalContext *lc, int x0, int y0, int width, int height, int c_idx, vvc355_intra_job *job);
 void vvc355_ctx_flatten_cclm(const VVCLocalContext *lc, int x0, int y0, int width, int height, vvc355_cclm_job *job);
-/* returns 1 when the per-CTU cache already holds this VPDU's scale (no job needed), else fills the job */
-int  vvc355_ctx_flatten_lmcs_scale(const VVCLocalContext *lc, int x0_cu, int y0_cu, vvc355_lmcs_scale_job *job);
-/* the availability process on the mirror (ff_vvc_get_top_available / _left_available, vvc_intra.c:591-648) */
+void vvc355_ctx_flatten_lmcs_scale(const VVCLocalContext *lc, int x0_cu, int y0_cu, vvc355_lmcs_scale_job *job);
+/* Reference-sample availability (the question ff_vvc_get_top_available / _left_available answer, vvc_intra.c:591-648).  The shim's own
+ * derivation works from a coverage mask of the neighbouring line (dsp_ctx_shim.c); an in-tree build installs the decoder's own two
+ * functions instead: vvc355_ctx_set_availability(ff_vvc_get_top_available, ff_vvc_get_left_available).  NULL = the shim's own. */
+typedef int (*vvc355_avail_fn)(const VVCLocalContext *lc, int x, int y, int target_size, int c_idx);
+void vvc355_ctx_set_availability(vvc355_avail_fn top, vvc355_avail_fn left);
 int  vvc355_ctx_top_available(const VVCLocalContext *lc, int x, int y, int target_size, int c_idx);
 int  vvc355_ctx_left_available(const VVCLocalContext *lc, int x, int y, int target_size, int c_idx);
 

@@ -98,7 +98,7 @@ class ReconWork:
         cu = (x, y, w, h)
         mode = int(rng.choice([0, 1, 18, 50] + list(range(2, 67))))
         y0b = y & (ctb - 1)
-        isp = tools and w >= 8 and h >= 16 and rng.random() < 0.15
+        isp = tools and h <= 64 and ((w >= 8 and h >= 16) or (w in (4, 8, 16) and h >= 8 and w * h >= 64 and rng.random() < 0.5)) and rng.random() < 0.15
         is_mip = tools and not isp and w <= 64 and h <= 64 and rng.random() < 0.1
         ref_idx = int(rng.choice([1, 2])) if (tools and y0b and not is_mip and not isp and mode != 0 and rng.random() < 0.15) else 0
         bdpcm = int(tools and mode in (18, 50) and not isp and not is_mip and w <= 32 and h <= 32 and rng.random() < 0.3)
@@ -108,12 +108,18 @@ class ReconWork:
             kw["mip_mode"], kw["mip_transposed"] = int(rng.integers(0, (16, 8, 6)[size_id])), int(rng.integers(0, 2))
         # luma (ch_type 0): one transform unit, or ISP's horizontal sub-partitions — predict, record, add the residual
         parts = [(x, y, w, h)]
-        if isp:
+        vertical = isp and w <= 16 and (h < 16 or rng.random() < 0.5)
+        if vertical:
+            # ISP_VER_SPLIT: four sub-partitions side by side, 1 / 2 / 4 samples wide for coding units 4 / 8 / 16 wide.  Below 4 samples the
+            # prediction covers 4 columns at once, on every (4 / width)-th sub-partition only (get_luma_predict_unit, vvc_intra.c:216-226)
+            parts = [(x + i * (w // 4), y, w // 4, h) for i in range(4)]
+        elif isp:
             k = 4 if h >= 32 else 2
             parts = [(x, y + i * h // k, w, h // k) for i in range(k)]
-        for (px, py, pw, ph) in parts:
-            out.append(self._cmd(abi.RECON_PRED, 0, px, py, pw, ph, *cu, **kw))
-            out.append(self._cmd(abi.RECON_MARK, 0, px, py, pw, ph, *cu))
+        for idx, (px, py, pw, ph) in enumerate(parts):
+            if pw >= 4 or idx % (4 // pw) == 0:
+                out.append(self._cmd(abi.RECON_PRED, 0, px, py, max(pw, 4), ph, *cu, **kw))
+                out.append(self._cmd(abi.RECON_MARK, 0, px, py, max(pw, 4), ph, *cu))
             if rng.random() < coded_p:
                 out.append(self._cmd(abi.RECON_RESID, 0, px, py, pw, ph, *cu, resid=self._resid(0, px, py, pw, ph)))
         # chroma (ch_type 1): both components predicted over the coding unit, then their residuals (joint Cb-Cr now and then)

@@ -20,7 +20,7 @@ def declared_symbols():
 # exported by the C host shim (libvvc_mi355_host.so): the table installers and the context flattening of include/vvc_mi355_ctx.h
 HOST_SYMBOLS = {"ff_vvc_dsp_init_mi355", "ff_vvc_dsp_init_mi355_ctx", "vvc355_dsp_count_slots", "vvc355_dsp_table_selftest",
                 "vvc355_ctx_flatten_cclm", "vvc355_ctx_flatten_intra_pred", "vvc355_ctx_flatten_lmcs_scale", "vvc355_ctx_left_available",
-                "vvc355_ctx_top_available"}
+                "vvc355_ctx_top_available", "vvc355_ctx_set_availability"}
 
 
 def test_library_exports_every_declared_symbol():

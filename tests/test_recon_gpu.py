@@ -86,3 +86,17 @@ def test_recon_more_ctus_than_workgroups(dev, orc):
     rng = np.random.default_rng(0x5EED0E99)
     work, changed = run_case(dev, orc, rng, 10, 1024, 576, 5, (1, 1), intra_frac=1.0, n_slices=2)
     assert len(work.order) == 32 * 18 and changed > 1024 * 576 // 2
+
+
+@pytest.mark.parametrize("bd,fmt,min_cu", [(10, (0, 0), 4), (8, (1, 1), 8), (12, (1, 0), 8)])
+def test_recon_vertical_isp_narrow_transform_blocks(dev, orc, bd, fmt, min_cu):
+    """Vertically split ISP coding units: sub-partitions 1 and 2 samples wide are predicted four columns at a time and get their
+    residuals added per sub-partition (get_luma_predict_unit, vvc_intra.c:216-226; add_residual with the transform block's size) —
+    the RESID command of a block narrower than four samples, at odd and even columns."""
+    rng = np.random.default_rng(0x5EED0EA0 + bd + min_cu)
+    work, changed = run_case(dev, orc, rng, bd, 328, 200, 6, fmt, intra_frac=1.0, min_cu=min_cu, split=(0.95, 0.8), coded_p=0.9)
+    res = work.cmds[work.cmds["kind"] == abi.RECON_RESID]
+    luma = res[res["c_idx"] == 0]
+    assert (luma["w"] == 2).sum() > 8
+    if min_cu == 4:
+        assert (luma["w"] == 1).sum() > 8 and ((luma["w"] == 1) & (luma["x0"] % 2 == 1)).sum() > 2

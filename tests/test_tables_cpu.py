@@ -1,5 +1,9 @@
-"""The constant tables the kernels use (exported by the built library as vvc355_tab_*) against the reference's own data file,
-without going through ffvvc_amd/csrc/tables.inc or its generator: tools/ref_tables.py reads libavcodec/vvc/vvc_data.c as data.
+"""The constant tables the kernels use (exported by the built library as vvc355_tab_*) against the reference's own files,
+without going through ffvvc_amd/csrc/tables.inc / tables_small.inc or their generator: tools/ref_tables.py reads
+libavcodec/vvc/vvc_data.c and the inline tables of vvc_filter.c, vvc_intra.c, vvc_intra_template.c and vvc_filter_template.c
+(Table 43, the intra angles, the level scale, the filtered modes and filter thresholds, CCLM's divSigTable, ALF's varTab and
+transpose index lists, the 4x4 diagonal scan) as data.  Where a kernel uses a packed or arithmetic form of such a table
+(intra.hip, itx.hip, alf.hip) a static_assert proves it equal to the exported initialiser at compile time.
 Where the reference is present (the build container) the values are compared one by one and the committed digests are checked to
 be current; everywhere (the GPU box has no reference) the library's tables are compared with the committed digests
 (tests/golden/tables_sha256.json).  The DCT-2 table has no counterpart in vvc_data.c (the reference hard-codes DCT-2 butterflies in
@@ -16,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import ref_tables  # noqa: E402
 
-CT = {"int8": ctypes.c_int8, "uint8": ctypes.c_uint8, "int16": ctypes.c_int16}
-FMT = {"int8": "b", "uint8": "B", "int16": "h"}
+CT = {"int8": ctypes.c_int8, "uint8": ctypes.c_uint8, "int16": ctypes.c_int16, "uint16": ctypes.c_uint16}
+FMT = {"int8": "b", "uint8": "B", "int16": "h", "uint16": "H"}
 
 
 def fixture():

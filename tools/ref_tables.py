@@ -77,7 +77,42 @@ def read_reference(path=REF):
     t["alf_aps_class_to_filt_map"] = ("B", _numbers(_initialiser(text, "ff_vvc_alf_aps_class_to_filt_map")))
     for n in ("mip_matrix_4x4", "mip_matrix_8x8", "mip_matrix_16x16"):
         t[n] = ("B", _numbers(_initialiser(text, n)))
+    # ---- the tables the reference keeps inline in other files (function-local `static const` arrays)
+    d = os.path.dirname(path)
+    flt, intra, intra_t, flt_t = (_strip(open(os.path.join(d, f)).read()) for f in ("vvc_filter.c", "vvc_intra.c", "vvc_intra_template.c", "vvc_filter_template.c"))
+    t["tc_table"] = ("H", _numbers(_initialiser(flt, "tctable")))                              # vvc_filter.c:38
+    t["beta_table"] = ("B", _numbers(_initialiser(flt, "betatable")))                          # :47
+    t["intra_angles"] = ("h", _numbers(_initialiser(intra, "angles")))                         # vvc_intra.c:667
+    t["level_scale"] = ("B", _numbers(_initialiser(intra, "level_scale")))                     # :329
+    t["ref_filter_modes"] = ("b", _numbers(_initialiser(intra, "modes").replace("INTRA_PLANAR", "0")))      # :657 (INTRA_PLANAR = 0, vvc_ctu.h)
+    t["intra_filter_thres"] = ("B", _numbers(_initialiser(intra_t, "intra_hor_ver_dist_thres")))            # vvc_intra_template.c:559
+    t["cclm_div_sig"] = ("B", _numbers(_initialiser(intra_t, "div_sig_table")))                # :261
+    t["alf_arg_var"] = ("B", _numbers(_initialiser(flt_t, "arg_var")))                         # vvc_filter_template.c:272
+    t["alf_transpose_index"] = ("B", _numbers(_initialiser(flt_t, "index")))                   # :387
+    for axis in "xy":
+        t[f"diag_scan_4x4_{axis}"] = ("B", _sub_initialiser(_initialiser(text, f"ff_vvc_diag_scan_{axis}"), (2, 2)))   # vvc_data.c:27,152: [log2 w][log2 h]
     return t
+
+
+def _sub_initialiser(body, index):
+    """Numbers of the sub-aggregate body[index[0]][index[1]]... of a nested brace initialiser (rows may be shorter than their bound)."""
+    for want in index:
+        depth, seen, start = 0, -1, None
+        for i, ch in enumerate(body):
+            if ch == "{":
+                if depth == 0:
+                    seen += 1
+                    if seen == want:
+                        start = i + 1
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+                if depth == 0 and start is not None:
+                    body = body[start:i]
+                    break
+        else:
+            raise IndexError(index)
+    return _numbers(body)
 
 
 def digest(fmt, values):
@@ -86,9 +121,9 @@ def digest(fmt, values):
 
 def main():
     t = read_reference()
-    fix = {name: {"type": {"b": "int8", "B": "uint8", "h": "int16"}[fmt], "count": len(v), "sha256": digest(fmt, v)} for name, (fmt, v) in sorted(t.items())}
+    fix = {name: {"type": {"b": "int8", "B": "uint8", "h": "int16", "H": "uint16"}[fmt], "count": len(v), "sha256": digest(fmt, v)} for name, (fmt, v) in sorted(t.items())}
     with open(FIXTURE, "w") as f:
-        json.dump({"source": "libavcodec/vvc/vvc_data.c of the reference, read by tools/ref_tables.py", "tables": fix}, f, indent=1)
+        json.dump({"source": "libavcodec/vvc/vvc_data.c, vvc_filter.c, vvc_intra.c, vvc_intra_template.c, vvc_filter_template.c of the reference, read by tools/ref_tables.py", "tables": fix}, f, indent=1)
         f.write("\n")
     print("wrote", FIXTURE, len(fix), "tables")
 
