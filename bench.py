@@ -86,6 +86,8 @@ class Frame:
         self.host = {}        # data_ptr -> host copy of every uploaded table (what the `verified` leg mirrors for the oracle)
         self.torch_of = {}
         self.noise = False
+        self.ref_frames = None                 # (Frame, Frame): reference pictures = those frames' decoded output (GOP mode); None: synthetic pictures
+        self.out = self.planes(False)          # the decoded picture (ALF output); allocated first so that other frames can refer to it
 
     def picture(self, c, pad, like=None, shift=(0, 0), sigma=2.0):
         """One plane of a reference picture (component c) with a `pad`-sample apron; `like` = displaced noisy copy of that plane."""
@@ -167,14 +169,22 @@ def build_chain(lib, torch, fr):
     ptr = lambda t: t.data_ptr()          # noqa: E731
     chain = []
 
-    # two reference pictures; the second is the first displaced by (+2, -2) luma samples plus noise: ref1[y, x] = ref0[y + 2, x - 2]
-    ref0 = [fr.picture(c, Frame.PAD) for c in range(3)]
-    ref1 = [fr.picture(c, Frame.PAD, like=ref0[c], shift=(-2 >> (c > 0), 2 >> (c > 0))) for c in range(3)]
-    ref = [ref0, ref1]
+    if fr.ref_frames is None:
+        # two synthetic reference pictures; the second is the first displaced by (+2, -2) luma samples plus noise: ref1[y, x] = ref0[y + 2, x - 2]
+        ref0 = [fr.picture(c, Frame.PAD) for c in range(3)]
+        ref1 = [fr.picture(c, Frame.PAD, like=ref0[c], shift=(-2 >> (c > 0), 2 >> (c > 0))) for c in range(3)]
+        ref = [ref0, ref1]
+        ref_org = lambda r, c: ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz          # noqa: E731  sample (0, 0) of the picture
+    else:
+        # the decoded pictures (ALF output planes) of two other frames of the GOP: what the DPB hands an inter picture.  No apron: every
+        # prediction kernel of the chain reads at coordinates clamped to the picture (the reference's edge emulation)
+        ref = [fr.ref_frames[0].out, fr.ref_frames[1].out]
+        ref_org = lambda r, c: ptr(ref[r][c])          # noqa: E731
+    ref_pitch = lambda r, c: fr.pitch(ref[r][c])       # noqa: E731
     fr.refs = ref
     rec = fr.planes(False)                                               # prediction -> reconstruction -> deblocked
     sao = fr.planes(False)
-    out = fr.planes(False)
+    out = fr.out
     pitches = [fr.pitch(t) for t in rec]
     rec_ptrs = [ptr(t) for t in rec]
 
@@ -219,8 +229,8 @@ def build_chain(lib, torch, fr):
             j["dst"] = ptr(rec[c]) + (y0 >> sh) * fr.pitch(rec[c]) + (x0 >> sh) * isz
             j["dst_stride"] = fr.pitch(rec[c])
             for r, key in enumerate(("ref0", "ref1")):
-                j[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz        # sample (0, 0) of the picture
-                j[key + "_stride"] = fr.pitch(ref[r][c])
+                j[key] = ref_org(r, c)        # sample (0, 0) of the picture
+                j[key + "_stride"] = ref_pitch(r, c)
             j["rec"] = ptr(d_rec) + np.arange(n_blk, dtype=np.int64) * 32
             j["mv"] = mv
             j["x"], j["y"], j["w"], j["h"] = x0 >> sh, y0 >> sh, bs >> sh, bs >> sh
@@ -253,8 +263,8 @@ def build_chain(lib, torch, fr):
         reft = (abi.RefPic * 32)()
         for l in range(2):
             for c in range(3):
-                reft[l * 16].plane[c] = ptr(ref[l][c]) + Frame.PAD * fr.pitch(ref[l][c]) + Frame.PAD * isz
-                reft[l * 16].stride[c] = fr.pitch(ref[l][c])
+                reft[l * 16].plane[c] = ref_org(l, c)
+                reft[l * 16].stride[c] = ref_pitch(l, c)
         d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
         d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(abi.InterSlice()), np.uint8))
         d_bl = torch.zeros(luma_jobs.nbytes, dtype=torch.uint8, device="cuda")
@@ -321,8 +331,8 @@ def build_chain(lib, torch, fr):
             b["dst"] = ptr(rec[c]) + (yg0 >> sh) * fr.pitch(rec[c]) + (xg0 >> sh) * isz
             b["dst_stride"] = fr.pitch(rec[c])
             for r, key in enumerate(("ref0", "ref1")):
-                b[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz
-                b[key + "_stride"] = fr.pitch(ref[r][c])
+                b[key] = ref_org(r, c)
+                b[key + "_stride"] = ref_pitch(r, c)
             b["mv"] = gmv
             b["x"], b["y"], b["w"], b["h"], b["pic_w"], b["pic_h"] = xg0 >> sh, yg0 >> sh, 16 >> sh, 16 >> sh, w, h
             b["chroma"], b["hs"], b["vs"] = int(c > 0), 1, 1
@@ -372,8 +382,8 @@ def build_chain(lib, torch, fr):
         afj["dst"] = ptr(rec[0]) + ay * fr.pitch(rec[0]) + ax * isz
         afj["dst_stride"] = fr.pitch(rec[0])
         for r, key in enumerate(("ref0", "ref1")):
-            afj[key] = ptr(ref[r][0]) + Frame.PAD * fr.pitch(ref[r][0]) + Frame.PAD * isz
-            afj[key + "_stride"] = fr.pitch(ref[r][0])
+            afj[key] = ref_org(r, 0)
+            afj[key + "_stride"] = ref_pitch(r, 0)
         d_dmv = fr.upload(rng.integers(-32, 33, size=(2, 2, 16)).astype(np.int16))
         afj["diff_mv"] = ptr(d_dmv)
         afj["mv"] = base_mv + rng.integers(-8, 9, size=(n_sb, 4))
@@ -385,8 +395,8 @@ def build_chain(lib, torch, fr):
             j["dst"] = ptr(rec[c]) + (ya0 >> 1) * fr.pitch(rec[c]) + (xa0 >> 1) * isz
             j["dst_stride"] = fr.pitch(rec[c])
             for r, key in enumerate(("ref0", "ref1")):
-                j[key] = ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz
-                j[key + "_stride"] = fr.pitch(ref[r][c])
+                j[key] = ref_org(r, c)
+                j[key + "_stride"] = ref_pitch(r, c)
             j["mv"] = base_mv[::16]
             j["x"], j["y"], j["w"], j["h"] = xa0 >> 1, ya0 >> 1, 8, 8
             j["pic_w"], j["pic_h"] = fr.dims[c]
@@ -450,8 +460,8 @@ def build_chain(lib, torch, fr):
         cjobs["dst"] = ptr(d_ciip) + cj[:, 5] * isz
         cjobs["dst_stride"] = cj[:, 6] * isz
         for r, key in enumerate(("ref0", "ref1")):
-            cjobs[key] = np.array([ptr(ref[r][c]) + Frame.PAD * fr.pitch(ref[r][c]) + Frame.PAD * isz for c in range(3)], np.int64)[cc]
-            cjobs[key + "_stride"] = np.array([fr.pitch(ref[r][c]) for c in range(3)], np.int64)[cc]
+            cjobs[key] = np.array([ref_org(r, c) for c in range(3)], np.int64)[cc]
+            cjobs[key + "_stride"] = np.array([ref_pitch(r, c) for c in range(3)], np.int64)[cc]
         cmv = rng.integers(-24 * 16, 24 * 16 + 1, size=(len(work.ciip), 4))
         # every tile of a coding unit shares its motion: index of the CU each tile came from
         cu_of_tile = np.repeat(np.arange(len(work.ciip)), [((w >> (1 if c else 0)) + 15) // 16 * (((h >> (1 if c else 0)) + 15) // 16) for (c, x, y, w, h, off, _k) in work.ciip])
@@ -943,10 +953,14 @@ def build_chain(lib, torch, fr):
             bad = sum(int(not np.array_equal(w_[:d_[1], :d_[0]], env.after[ptr(t)][:d_[1], :d_[0]])) for t, w_, d_ in zip(out, work, fr.dims))
             return fr.n_ctus, bad
 
-        chain.append(Stage("alf", f"alf_luma_kernel<{bd}, 1> + alf_chroma_kernel<{bd}> + alf_cc_kernel<{bd}> (+ alf_build_kernel)",
-                           lambda st: lib.vvc355_alf_frame_pass(st, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork)),
-                           fr.width * fr.height * isz * 2 + chroma_bytes * 2 + chroma_bytes * 2 + fr.width * fr.height * isz,
-                           writes=out, check=check_alf))
+        # ALF (luma + chroma + CC) = every sample read once and written once, 4 B per sample at 10 bits.  The CTB kernel
+        # does exactly that (the luma tile also serves CC-ALF); implementation_bytes adds its aprons (3 luma / 2 chroma samples per CTB side)
+        alf_alg = (fr.width * fr.height + chroma_bytes // isz) * isz * 2
+        st_alf = Stage("alf", f"alf_ctb_kernel<{bd}, true> (+ alf_build_kernel)",
+                       lambda st: lib.vvc355_alf_frame_pass(st, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork)),
+                       alf_alg, writes=out, check=check_alf)
+        st_alf.implementation_bytes = alf_alg + fr.n_ctus * ((134 * 144 - 128 * 128) + 2 * (68 * 80 - 64 * 64)) * isz
+        chain.append(st_alf)
         return chain
 
     # ---------------------------------------------------------------- ALF luma: classify + coefficient gather + 7x7 diamond, fused
@@ -1364,6 +1378,21 @@ def stub_main(args, world, rank, dist):
         dist.destroy_process_group()
 
 
+def gop_order(g):
+    """Decoding order of a hierarchical-B group of pictures of size g (a power of two) as (POC, lower reference POC, upper reference
+    POC): POC g from POC 0 (the previous group's POC g) on both lists, then every interval's middle picture from the interval's two
+    ends, coarsest level first — the random-access structure of the VVC common test conditions."""
+    out, level = [(g, 0, 0)], [(0, g)]
+    while level and level[0][1] - level[0][0] > 1:
+        nxt = []
+        for lo, hi in level:
+            mid = (lo + hi) // 2
+            out.append((mid, lo, hi))
+            nxt += [(lo, mid), (mid, hi)]
+        level = nxt
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1373,7 +1402,10 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--bd", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=8, help="independent frames processed concurrently per step (one HIP stream each); 1 = latency of a single frame")
+    ap.add_argument("--gop", type=int, default=16, help="pictures per hierarchical-B group (a power of two): a step decodes one group of one stream, every picture "
+                                                        "behind its two reference pictures; 0 = independent frames (--frames-in-flight)")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="independent frames processed concurrently per step (one HIP stream each): the whole step with --gop 0, "
+                                                                    "the secondary `independent_frames` figure otherwise; 1 = latency of a single frame")
     ap.add_argument("--with-upload", action="store_true", help="additionally time the steps with every per-frame descriptor copied from pinned host memory first")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
@@ -1428,42 +1460,108 @@ def main(argv=None):
     lib = abi.load()
     lib.vvc355_set_device(local_rank)
 
-    # F independent frames in flight per step, each on its own HIP stream — how a frame-parallel decoder keeps the device busy (the
-    # reference decodes several frames at once: frame threads, libavcodec/vvc/vvc_thread.c; SURVEY 8d sizes batches in frames in
-    # flight).  The in-order intra pass of one frame (a dependent chain, few waves) then overlaps the other frames' throughput
-    # kernels.  --frames-in-flight 1 measures the latency of one frame instead.
+    # ---- the frames of a step
+    # GOP mode (default, --gop 16): a step decodes one hierarchical-B group of pictures of ONE stream — POC G from the previous group's
+    # POC G, then G/2 from (0, G), G/4 and 3G/4, ... — every picture's inter prediction reading the decoded output (ALF planes) of its
+    # two reference pictures, every picture on a HIP stream of its own behind event waits on its references (what the reference's
+    # frame threads do with ff_vvc_report_progress / vvc_refs.h:37-56, at picture granularity).  Consecutive groups overlap: group
+    # k + 1 only needs group k's POC G.  Three rotating sets of G frame objects keep a picture's buffers untouched until nothing reads
+    # them any more (a decoder's DPB does the same with fresh frame buffers): group k uses set k % 3 and starts after group k - 2.
+    # --gop 0: F independent frames per step (--frames-in-flight), no dependencies: the device's throughput ceiling.
+    gop = max(0, args.gop)
     n_ff = max(1, args.frames_in_flight)
-    frames, chains, streams = [], [], []
-    for i in range(n_ff):
-        fr_i = Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank + 977 * i)
-        fr_i.noise = args.noise
-        ch_i = build_chain(lib, torch, fr_i)
-        if args.only:
-            ch_i = [st for st in ch_i if st.name in args.only.split(",")]
-        frames.append(fr_i)
-        chains.append(ch_i)
-        streams.append(torch.cuda.Stream())
+    n_sets = 3
+    streams = [torch.cuda.Stream() for _ in range(16 if gop else n_ff)]
+    t_build = time.perf_counter()
+    if gop:
+        order = gop_order(gop)
+        objs = {(j, poc): Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank + 977 * (j * gop + poc)) for j in range(n_sets) for poc in range(1, gop + 1)}
+
+        def ref_obj(j, poc):
+            return objs[((j - 1) % n_sets, gop)] if poc == 0 else objs[(j, poc)]
+        chains_of = {}
+        for (j, poc), fr_i in objs.items():
+            lo, hi = next((lo_, hi_) for (p_, lo_, hi_) in order if p_ == poc)
+            fr_i.noise = args.noise
+            fr_i.ref_frames = (ref_obj(j, lo), ref_obj(j, hi))
+        for key, fr_i in objs.items():
+            # every picture starts out as picture-like content, so that the first groups predict from something sensible
+            for c in range(3):
+                fr_i.out[c].copy_(fr_i.picture(c, 0)[:, :fr_i.out[c].shape[1]])
+                fr_i.keep.pop()
+            ch_i = build_chain(lib, torch, fr_i)
+            chains_of[key] = [st for st in ch_i if st.name in args.only.split(",")] if args.only else ch_i
+        frames = [objs[(0, poc)] for poc in range(1, gop, 2)][:n_ff] or [objs[(0, 1)]]        # the odd POCs of a group do not depend on each other
+        chains = [chains_of[(0, poc)] for poc in range(1, gop, 2)][:n_ff] or [chains_of[(0, 1)]]
+        n_ff = len(frames)
+        done_ev = {key: torch.cuda.Event() for key in objs}
+        recorded = set()
+        gop_ev = [torch.cuda.Event() for _ in range(n_sets)]
+        join_stream = torch.cuda.Stream()
+    else:
+        frames, chains = [], []
+        for i in range(n_ff):
+            fr_i = Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank + 977 * i)
+            fr_i.noise = args.noise
+            ch_i = build_chain(lib, torch, fr_i)
+            if args.only:
+                ch_i = [st for st in ch_i if st.name in args.only.split(",")]
+            frames.append(fr_i)
+            chains.append(ch_i)
     frame, chain = frames[0], chains[0]
     torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build
 
     # events are created before the timed region; inside it they are only recorded
     pool = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chain] for _ in range(args.steps)]
 
-    def run_frame(f, events=None, step=0, only=None):
-        sh = streams[f].cuda_stream
+    def run_frame(f, events=None, step=0, only=None, stream=None):
+        ts = stream if stream is not None else streams[f % len(streams)]
+        sh = ts.cuda_stream
         for i, st in enumerate(chains[f]):
             if f == 0 and events is not None and (only is None or st.name == only):
                 e0, e1 = pool[step][i]
-                e0.record(streams[0])
+                e0.record(ts)
                 st.launch(sh)
-                e1.record(streams[0])
+                e1.record(ts)
                 events.setdefault(st.name, []).append((e0, e1))
             else:
                 st.launch(sh)
 
-    def run_step(events=None, step=0, only=None):
+    def run_independent(events=None, step=0, only=None):
         for f in range(n_ff):
             run_frame(f, events, step, only)
+
+    def run_gop(k, events=None, step=0, only=None):
+        j = k % n_sets
+        for i, (poc, lo, hi) in enumerate(order):
+            ts = streams[i % len(streams)]
+            for dep in {((j - 1) % n_sets, gop) if q == 0 else (j, q) for q in (lo, hi)}:
+                if dep in recorded:
+                    ts.wait_event(done_ev[dep])
+            if k >= 2:
+                ts.wait_event(gop_ev[(k - 2) % n_sets])            # nothing reads this set's pictures any more
+            if (j, poc) == (0, 1) and events is not None:           # the frame whose dominant stage carries the events
+                run_frame(0, events, step, only, stream=ts)
+            else:
+                sh = ts.cuda_stream
+                for st in chains_of[(j, poc)]:
+                    st.launch(sh)
+            done_ev[(j, poc)].record(ts)
+            recorded.add((j, poc))
+        for (poc, _lo, _hi) in order:
+            join_stream.wait_event(done_ev[(j, poc)])
+        gop_ev[j].record(join_stream)
+
+    gop_k = [0]
+
+    def run_step(events=None, step=0, only=None):
+        if gop:
+            run_gop(gop_k[0], events, step, only)
+            gop_k[0] += 1
+        else:
+            run_independent(events, step, only)
+    frames_per_step = gop if gop else n_ff
 
     def barrier():
         sharding.barrier(dist, world, torch.cuda.synchronize)
@@ -1472,7 +1570,7 @@ def main(argv=None):
         run_step()
     barrier()
     # Untimed pass of ONE frame alone with HIP events around every stage: the per-stage breakdown (`stages`), the latency of a frame
-    # and which stage dominates.  The timed region then carries events around that one stage only (the roofline figure).
+    # and which stage dominates.  The timed region then carries events around that one stage only.
     events = {}
     t_lat = time.perf_counter()
     for k in range(args.steps):
@@ -1482,13 +1580,29 @@ def main(argv=None):
     breakdown = {name: float(np.mean([a.elapsed_time(b) for a, b in ev])) for name, ev in events.items()}
     # the in-order intra pass is a latency-bound dependent chain on a few hundred waves; with several frames in flight it runs
     # beside the other frames' kernels, so the kernel that bounds throughput is the largest of the batched stages
-    throughput_stages = {k: v for k, v in breakdown.items() if not (n_ff > 1 and k == "intra_recon_wavefront")} or breakdown
+    throughput_stages = {k: v for k, v in breakdown.items() if k != "intra_recon_wavefront"} or breakdown
     dom_name = max(throughput_stages, key=throughput_stages.get)
+    barrier()
+    # secondary figure: F mutually independent frames per step (in GOP mode: the odd pictures of one group) — the ceiling without
+    # reference dependencies
+    independent = None
+    if gop and not args.graph:
+        for _ in range(2):
+            run_independent()
+        torch.cuda.synchronize()
+        t_i = time.perf_counter()
+        n_i = max(4, args.steps // 2)
+        for _ in range(n_i):
+            run_independent()
+        torch.cuda.synchronize()
+        el_i = sharding.max_over_ranks(dist, torch, world, time.perf_counter() - t_i, "cpu")
+        independent = {"value": world * n_ff * n_i / el_i, "unit": "frames/s", "frames_in_flight": n_ff, "steps": n_i,
+                       "note": "mutually independent frames (the odd pictures of one group), one HIP stream each, no reference waits: not a decode rate"}
     barrier()
     events = {}
     if args.graph:
         # the timed region replays one captured hipGraph per frame in flight and step (one launch per frame instead of ~30), each on a
-        # stream of its own; no events inside it
+        # stream of its own; no events inside it (independent-frames mode only)
         gstreams = [lib.vvc355_stream_create() for _ in range(n_ff)]
         gexecs = []
         for f in range(n_ff):
@@ -1508,6 +1622,7 @@ def main(argv=None):
         for f in range(n_ff):
             lib.vvc355_stream_sync(gstreams[f])
         elapsed = time.perf_counter() - t0
+        frames_per_step = n_ff
     else:
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -1517,9 +1632,9 @@ def main(argv=None):
     barrier()
     elapsed = sharding.max_over_ranks(dist, torch, world, elapsed, "cpu")
 
-    # second figure: the same steps with every per-frame descriptor (job arrays, side tables, command lists) copied from pinned host
+    # second figure: the same frames with every per-frame descriptor (job arrays, side tables, command lists) copied from pinned host
     # memory at the start of each frame — what a decoder that builds them on the host pays over PCIe (the coefficient levels, which
-    # are generated on the device here, are not included: their size is reported)
+    # are generated on the device here, are not included: their size is reported).  Measured on the F independent frames.
     upload = None
     if args.with_upload and not args.graph:
         pinned = [[(frames[f].torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in frames[f].host.items()] for f in range(n_ff)]
@@ -1527,7 +1642,7 @@ def main(argv=None):
 
         def run_step_upload():
             for f in range(n_ff):
-                with torch.cuda.stream(streams[f]):
+                with torch.cuda.stream(streams[f % len(streams)]):
                     for dst_t, src_t in pinned[f]:
                         dst_t.copy_(src_t, non_blocking=True)
                 run_frame(f)
@@ -1539,36 +1654,44 @@ def main(argv=None):
         torch.cuda.synchronize()
         el_up = sharding.max_over_ranks(dist, torch, world, time.perf_counter() - t1, "cpu")
         upload = {"value": world * n_ff * args.steps / el_up, "unit": "frames/s", "descriptor_bytes_per_frame": int(up_bytes),
-                  "ms_per_step": el_up / args.steps * 1e3,
+                  "ms_per_step": el_up / args.steps * 1e3, "frames_in_flight": n_ff,
                   "not_included": "coefficient levels (int32 in the reference ABI, generated on the device here)"}
 
     if rank == 0:
-        stage_ms = dict(breakdown)
-        if dom_name in events:                        # the dominant stage as measured inside the timed region
-            stage_ms[dom_name] = float(np.mean([a.elapsed_time(b) for a, b in events[dom_name]]))
         stages = {}
+        kernel_ms_total = sum(breakdown.values())
         for st in chain:
-            gbs = st.algorithmic_bytes / (stage_ms[st.name] * 1e-3) / 1e9
-            stages[st.name] = {"kernel": st.kernel, "ms": stage_ms[st.name], "algorithmic_bytes": st.algorithmic_bytes,
-                               "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+            gbs = st.algorithmic_bytes / (breakdown[st.name] * 1e-3) / 1e9
+            stages[st.name] = {"kernel": st.kernel, "ms": breakdown[st.name], "algorithmic_bytes": st.algorithmic_bytes,
+                               "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "share_of_frame_kernel_time": breakdown[st.name] / kernel_ms_total}
             if getattr(st, "extra", None):
                 stages[st.name].update(st.extra)
                 if "longest_dependency_chain_commands" in st.extra:
-                    stages[st.name]["us_per_command_on_the_chain"] = stage_ms[st.name] * 1e3 / max(1, st.extra["longest_dependency_chain_commands"])
-        dom = next(st for st in chain if st.name == dom_name)         # the kernel the step time is dominated by
-        achieved = stages[dom.name]["GB/s"]
+                    stages[st.name]["us_per_command_on_the_chain"] = breakdown[st.name] * 1e3 / max(1, st.extra["longest_dependency_chain_commands"])
+        dom = next(st for st in chain if st.name == dom_name)         # the batched stage with the largest launch time
+        in_region = float(np.mean([a.elapsed_time(b) for a, b in events[dom_name]])) if events.get(dom_name) else None
+        recon_ms = breakdown.get("intra_recon_wavefront")
+        if gop:
+            work = (f"one hierarchical-B group of {gop} pictures of one stream per step (decode order {' '.join(str(p_) for p_, _l, _h in order)}; every picture's inter "
+                    f"prediction reads the decoded output of its two reference pictures and starts behind their ALF stage; consecutive groups overlap; "
+                    f"{n_sets} rotating sets of {gop} frame buffers)")
+            par = f"one picture per HIP stream ({len(streams)} streams), event waits on the reference pictures"
+        else:
+            work = f"{n_ff} independent frame(s) in flight per step, one HIP stream each, no reference dependencies"
+            par = f"{n_ff} frame(s) in flight per GPU, one HIP stream each"
         out = {
             "metric": "decoded frames/sec (4K/8K 10-bit VVC) per GPU",
             "parity": "device output == in-repo CPU oracle on this frame (`verified`: sampled CTUs per prediction / transform stage, whole picture "
                       "for the loop-filter stages); the oracle itself is unpinned (no FATE bitstreams or reference build in this environment)",
-            "value": world * n_ff * args.steps / elapsed,
+            "value": world * frames_per_step * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "frames_per_step": n_ff,
+            "frames_per_step": frames_per_step,
             "frame_latency_ms": frame_latency_ms,          # one frame alone, stage after stage (untimed pass): latency, not throughput
+            "independent_frames": independent,             # the same frames without reference dependencies: a ceiling, not a decode rate
             "incl_descriptor_upload": upload,
             "higher_is_better": True,
             "scaling": "weak",
@@ -1576,37 +1699,39 @@ def main(argv=None):
             "dtype": "u8" if args.bd == 8 else "u16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access frame = {frame.n_ctus} CTUs of 128x128 "
-                            f"({n_ff} independent frame(s) in flight per step, one HIP stream each; per frame {INTER_FRAC:.0%} inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
+                "workload": f"{args.width}x{args.height} {args.bd}-bit 4:2:0 random-access pictures = {frame.n_ctus} CTUs of 128x128 each; {work}; "
+                            f"per picture {INTER_FRAC:.0%} inter CTUs: regular bi-prediction with DMVR + BDOF, {GPM_FRAC:.0%} of the blocks geometric partitions, {AFFINE_FRAC:.0%} of the CTUs affine + PROF, "
                             f"{CIIP_FRAC:.0%} of all CTUs combined inter / intra; {1 - INTER_FRAC:.0%} intra CTUs reconstructed in decoding order with LFNST / implicit MTS; "
-                            f"{'uniform-noise' if args.noise else 'picture-like'} content), one frame per GPU per step, HBM-resident; "
-                            f"stages per step: {', '.join(st.name for st in chain)}",
+                            f"{'uniform-noise' if args.noise else 'picture-like'} content; HBM-resident; "
+                            f"stages per picture: {', '.join(st.name for st in chain)}",
                 "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and INTER_FRAC == 0.8 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --inter-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
-                "parallelism": f"{world} independent frame stream(s), one per GPU, no collective; {n_ff} frame(s) in flight per GPU, one HIP stream each, "
-                               f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
+                "parallelism": f"{world} independent stream(s), one per GPU, no collective; {par}, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
+                "frame_objects_built": len(objs) if gop else n_ff, "build_s": round(build_s, 1),
             },
             "roofline": {
                 "stage": dom.name,
                 "kernel": dom.kernel,
                 "bound": "hbm",
-                # HIP events on the launch stream around the stage, one frame alone (the K-step pass right before the timed region):
-                # the kernels' own duration, which is what rocprofv3's per-kernel average of `--frames-in-flight 1` shows
-                # (profiles/r02_bench_f1_kernel_stats.csv).  Inside the timed region the other frames in flight share the device and an
-                # event pair also spans the time the stage's kernels wait for CUs: `in_timed_region`.
+                # duration: HIP events on the launch stream around the stage, one frame alone (the K-step pass right before the timed
+                # region) = the kernels' own duration, which is what rocprofv3's per-kernel average of one frame in flight shows
+                # (profiles/r03_bench_f1_kernel_stats.csv).  bytes: SURVEY.md 8(d)'s compulsory traffic (ALF: 4 B per sample).
                 "achieved": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": dom.algorithmic_bytes / (breakdown[dom.name] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ms_per_launch": breakdown[dom.name],
                 "algorithmic_bytes_per_launch": dom.algorithmic_bytes,
-                "in_timed_region": {"ms_per_launch": stage_ms[dom.name], "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                    "frames_in_flight": n_ff},
-                "note": ("dominant = the batched stage with the largest launch time; the in-order intra pass (intra_recon_wavefront) is a latency-bound "
-                         "dependent chain on a few hundred waves that overlaps the other frames in flight — see stages / frame_latency_ms") if n_ff > 1 else "",
-                "traffic": None,                          # PMC counters are collected in separate rocprofv3 passes: see `recorded`
-                # NOT measured in this run: counter passes of an earlier run of the same command, committed under profiles/
+                "implementation_bytes_per_launch": getattr(dom, "implementation_bytes", None),
+                "in_timed_region": None if in_region is None else {"ms_per_launch": in_region, "note": "event pair around the same stage while the other pictures share the device: "
+                                                                                                    "includes the time its kernels wait for CUs"},
+                # the longest kernel of a picture is not this stage but the in-order intra pass: a latency-bound dependency chain on a few
+                # hundred waves (21 MB of traffic), which the other pictures' batched stages overlap
+                "in_order_intra_pass": None if recon_ms is None else {"ms": recon_ms, "share_of_frame_kernel_time": recon_ms / kernel_ms_total,
+                                                                      "note": "longest kernel of a picture; excluded from `stage` because it is bound by its dependency chain, not by bandwidth"},
+                "note": "dominant = the batched stage with the largest launch time (stages / frame_latency_ms list every stage of one picture alone)",
+                "traffic": recorded_traffic(ROOT, dom.name),      # L2 <-> fabric bytes per launch from separate rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json)
                 "recorded": {"source": "profiles/pmc_traffic.json, profiles/mc_valu.json (rocprofv3 --pmc passes, see profiles/README.md)",
-                             "hbm_bytes_per_launch": recorded_traffic(ROOT, dom.name), "valu": recorded_valu(ROOT, dom.name)},
+                             "valu": recorded_valu(ROOT, dom.name)},
             },
             "stages": stages,
         }

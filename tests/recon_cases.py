@@ -16,7 +16,7 @@ class ReconWork:
     cmds["resid"] as ELEMENT offsets until `bind(base_address)` turns them into addresses."""
 
     def __init__(self, rng, width, height, ctb_log2=7, hs=1, vs=1, intra_frac=1.0, intra_ctu=None, cclm_frac=0.2, coded_p=0.7,
-                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True, ciip_frac=0.0, ciip_ctu=None):
+                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True, ciip_frac=0.0, ciip_ctu=None, isp_p=0.15):
         self.width, self.height, self.ctb_log2, self.hs, self.vs = width, height, ctb_log2, hs, vs
         ctb = 1 << ctb_log2
         self.ncx, self.ncy = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
@@ -36,6 +36,7 @@ class ReconWork:
         self.ciip = []                    # (c_idx, x0, y0, w, h luma units, pixel offset into the inter-prediction storage, command index)
         self.ciip_len = 0
         self.ciip_frac = ciip_frac
+        self.isp_p = isp_p
         for rs in range(n_ctb):
             rx, ry = rs % self.ncx, rs // self.ncx
             first = len(cmds)
@@ -98,7 +99,7 @@ class ReconWork:
         cu = (x, y, w, h)
         mode = int(rng.choice([0, 1, 18, 50] + list(range(2, 67))))
         y0b = y & (ctb - 1)
-        isp = tools and h <= 64 and ((w >= 8 and h >= 16) or (w in (4, 8, 16) and h >= 8 and w * h >= 64 and rng.random() < 0.5)) and rng.random() < 0.15
+        isp = tools and h <= 64 and ((w >= 8 and h >= 16) or (w in (4, 8, 16) and h >= 8 and w * h >= 64 and rng.random() < 0.5)) and rng.random() < self.isp_p
         is_mip = tools and not isp and w <= 64 and h <= 64 and rng.random() < 0.1
         ref_idx = int(rng.choice([1, 2])) if (tools and y0b and not is_mip and not isp and mode != 0 and rng.random() < 0.15) else 0
         bdpcm = int(tools and mode in (18, 50) and not isp and not is_mip and w <= 32 and h <= 32 and rng.random() < 0.3)

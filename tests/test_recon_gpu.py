@@ -94,9 +94,9 @@ def test_recon_vertical_isp_narrow_transform_blocks(dev, orc, bd, fmt, min_cu):
     residuals added per sub-partition (get_luma_predict_unit, vvc_intra.c:216-226; add_residual with the transform block's size) —
     the RESID command of a block narrower than four samples, at odd and even columns."""
     rng = np.random.default_rng(0x5EED0EA0 + bd + min_cu)
-    work, changed = run_case(dev, orc, rng, bd, 328, 200, 6, fmt, intra_frac=1.0, min_cu=min_cu, split=(0.95, 0.8), coded_p=0.9)
+    work, changed = run_case(dev, orc, rng, bd, 328, 200, 6, fmt, intra_frac=1.0, min_cu=min_cu, split=(0.95, 0.8), coded_p=0.9, isp_p=0.6)
     res = work.cmds[work.cmds["kind"] == abi.RECON_RESID]
     luma = res[res["c_idx"] == 0]
     assert (luma["w"] == 2).sum() > 8
     if min_cu == 4:
-        assert (luma["w"] == 1).sum() > 8 and ((luma["w"] == 1) & (luma["x0"] % 2 == 1)).sum() > 2
+        assert (luma["w"] == 1).sum() >= 4 and ((luma["w"] == 1) & (luma["x0"] % 2 == 1)).sum() >= 2
