@@ -273,8 +273,14 @@ class ReconFrame(ctypes.Structure):
         ("stride", ctypes.c_int32 * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
         ("ctb_height", ctypes.c_int32), ("n_work", ctypes.c_int32),
         ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("wpp", ctypes.c_uint8), ("collocated", ctypes.c_uint8),
-        ("pad_", ctypes.c_uint8 * 3),
+        ("pad_", ctypes.c_uint8 * 3), ("lmcs_model", ctypes.c_uint64),
     ]
+
+
+class LmcsModel(ctypes.Structure):
+    """Mirror of vvc355_lmcs_model / orc_lmcs_model."""
+    _fields_ = [("pivot", ctypes.c_uint16 * 17), ("chroma_scale_coeff", ctypes.c_uint16 * 16), ("min_bin_idx", ctypes.c_uint8), ("max_bin_idx", ctypes.c_uint8),
+                ("pad_", ctypes.c_uint8 * 4)]
 
 
 RECON_MARK, RECON_PRED, RECON_CCLM, RECON_RESID, RECON_CIIP = 0, 1, 2, 3, 4
@@ -294,6 +300,7 @@ class BipredJob(ctypes.Structure):
         ("chroma", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("dmvr", ctypes.c_uint8),
         ("bdof", ctypes.c_uint8), ("hf_idx", ctypes.c_uint8), ("vf_idx", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
         ("pred_flag", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 5),
+        ("lmcs_lut", ctypes.c_uint64),
     ]
 
 
@@ -313,6 +320,7 @@ class InterPu(ctypes.Structure):
 class InterSlice(ctypes.Structure):
     """Mirror of vvc355_inter_slice."""
     _fields_ = [("weighted_pred", ctypes.c_uint8), ("weighted_bipred", ctypes.c_uint8), ("log2_denom", ctypes.c_uint8 * 2),
+                ("lmcs_used", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
                 ("weight", ctypes.c_int16 * 16 * 3 * 2), ("offset", ctypes.c_int16 * 16 * 3 * 2)]
 
 
@@ -323,7 +331,7 @@ class InterFrame(ctypes.Structure):
                 ("dst_stride", ctypes.c_int32 * 3), ("mvf_stride", ctypes.c_int32), ("n_pus", ctypes.c_int32), ("n_jobs", ctypes.c_int32),
                 ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("chroma_format_idc", ctypes.c_uint8), ("pixel_shift", ctypes.c_uint8),
-                ("pad_", ctypes.c_uint8 * 4)]
+                ("pad_", ctypes.c_uint8 * 4), ("lmcs_fwd_lut", ctypes.c_uint64)]
 
 
 class GpmJob(ctypes.Structure):
@@ -428,6 +436,7 @@ class AffineJob(ctypes.Structure):
         ("denom", ctypes.c_int16), ("w0", ctypes.c_int16), ("w1", ctypes.c_int16), ("o0", ctypes.c_int16), ("o1", ctypes.c_int16),
         ("pred_flag", ctypes.c_uint8), ("prof0", ctypes.c_uint8), ("prof1", ctypes.c_uint8), ("weight_flag", ctypes.c_uint8),
         ("pad_", ctypes.c_uint8 * 6),
+        ("lmcs_lut", ctypes.c_uint64),
     ]
 
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void affine_kernel(const vvc355_affine_job *__
                 const int sh = job.denom + (prof ? max(2, 14 - BD) : 14 - BD);
                 out = ((p * job.w0 + (1 << (sh - 1))) >> sh) + job.o0 * (1 << (BD - 8));
             }
-            st_px<BD>(drow, x, clip_px<BD>(out));
+            st_px<BD>(drow, x, lmcs_fwd<BD>((const uint8_t *)job.lmcs_lut, clip_px<BD>(out)));
         }
     }
     if (bi) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void affine_kernel(const vvc355_affine_job *__
             const int sh = job.denom + max(3, 15 - BD);
             out = (a * job.w0 + b * job.w1 + ((((job.o0 + job.o1) << (BD - 8)) + 1) << (sh - 1))) >> sh;
         }
-        st_px<BD>(drow, x, clip_px<BD>(out));
+        st_px<BD>(drow, x, lmcs_fwd<BD>((const uint8_t *)job.lmcs_lut, clip_px<BD>(out)));
     }
 }
 

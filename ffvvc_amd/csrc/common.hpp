@@ -90,6 +90,13 @@ template <int BD> __device__ __forceinline__ void st_px(uint8_t *p, ptrdiff_t i,
     ((VVC355_GLOBAL typename Px<BD>::type *)p)[i] = (typename Px<BD>::type)v;
 }
 
+// lmcs.filter on one sample (vvc_filter_template.c:25): v -> lut[v]; lut = 0 (wave-uniform) leaves the sample as it is.  The inter
+// prediction kernels store luma through it when the job carries the picture's forward map (vvc_inter.c:888-891, :573-574).
+template <int BD> __device__ __forceinline__ int lmcs_fwd(const uint8_t *lut, int v)
+{
+    return lut ? (int)gld<typename Px<BD>::type>((const typename Px<BD>::type *)lut + v) : v;
+}
+
 // Address = wave-uniform base + unsigned 32-bit per-lane byte offset: the form the hardware takes directly (SGPR pair + VGPR
 // offset), so no 64-bit add per access.  Valid for planes below 4 GiB and offsets that are not negative.
 template <typename T> __device__ __forceinline__ T gld_at(const uint8_t *base, uint32_t off) { return gld<T>(base + (size_t)off); }

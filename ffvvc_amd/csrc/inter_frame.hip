@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void inter_build_kernel(const vvc355_inter_fra
                         j.bdof = !c && bi && pu.bdof_flag;
                         j.hf_idx = j.vf_idx = c ? 0 : pu.hpel_if_idx;
                         j.pred_flag = mv.pred_flag;
+                        // predict_inter's lmcs.filter (:888-891): luma of the coding unit goes through the forward map, CIIP units excepted
+                        j.lmcs_lut = (!c && sl->lmcs_used && !pu.ciip_flag) ? f.lmcs_fwd_lut : 0;
                         if (bi) {
                             // derive_weight (:149-177)
                             const int weight_flag = sl->weighted_pred || (sl->weighted_bipred && !pu.dmvr_flag);

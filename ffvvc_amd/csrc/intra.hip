@@ -1615,6 +1615,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     };
     int4 pre[4] = {};                    // residuals fetched one command ahead (the first 1024 of the block)
     int pre_k = -1;
+    int lmcs_xv = -1, lmcs_yv = -1, lmcs_scale = 0;      // lc->lmcs: the 64x64 unit whose chroma residual scale is known (reset per CTU, vvc_intra.c:509-510)
     while (i0 >= 0) {
         const uint32_t k = (uint32_t)i0;
         vvc355_recon_cmd c;
@@ -1737,17 +1738,57 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             const int *res = (const int *)c.resid;
             const int lw = ilog2i(w);
             const bool have = pre_k == (int)k;
+            const bool scaled = (c.joint & 8) != 0;
+            if (scaled && (lmcs_xv != (c.cu_x0 & ~(min(ctb, 64) - 1)) || lmcs_yv != (c.cu_y0 & ~(min(ctb, 64) - 1)))) {
+                // lmcs_derive_chroma_scale (vvc_intra_template.c:390-429): average of the reconstructed luma left of and above the 64x64 unit of
+                // the coding unit.  Every luma command before this one must be done (the unit's neighbours may be this CTU's own blocks).
+                while (recon_luma_done_get(L) < (int)k)
+                    __builtin_amdgcn_s_sleep(1);
+                group_sync<64>();
+                const int size_y = min(ctb, 64);
+                lmcs_xv = c.cu_x0 & ~(size_y - 1); lmcs_yv = c.cu_y0 & ~(size_y - 1);
+                const bool avail_t = __builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, lmcs_xv, lmcs_yv, 1, 0)) != 0;
+                const bool avail_l = __builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, lmcs_xv, lmcs_yv, 1, 0)) != 0;
+                StripRef s0 = st0;
+                s0.on = TILE && (lmcs_yv & ctb_mask) == 0;
+                int v = 0;
+                if (tid < size_y) {
+                    if (avail_l)
+                        v += pl0.ld((lmcs_yv + min(tid, min(f.height - lmcs_yv, size_y) - 1)) * ps0 + lmcs_xv - 1);        // lmcs_sum_samples: the last sample stands in beyond the picture
+                    if (avail_t) {
+                        const int xx = lmcs_xv + min(tid, min(f.width - lmcs_xv, size_y) - 1);
+                        v += s0.on ? s0.at(xx, -1) : pl0.ld((lmcs_yv - 1) * ps0 + xx);
+                    }
+                }
+#pragma unroll
+                for (int sft = 32; sft; sft >>= 1)
+                    v += __shfl_xor(v, sft, 64);
+                const int cnt = (avail_l ? size_y : 0) + (avail_t ? size_y : 0);
+                const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
+                const vvc355_lmcs_model *lm = (const vvc355_lmcs_model *)f.lmcs_model;
+                int bin = gld<uint8_t>(&lm->min_bin_idx);
+                const int last = gld<uint8_t>(&lm->max_bin_idx);
+                while (bin <= last && avg >= (int)gld<uint16_t>(&lm->pivot[bin + 1]))
+                    bin++;
+                lmcs_scale = __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&lm->chroma_scale_coeff[min(bin, 15)]));
+            }
+            auto resid_of = [&](int r) {                        // the joint sign / shift (pred_residual_joint), then lmcs_scale_chroma
+                if (c.joint & 1)
+                    r = (r * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
+                if (scaled) {
+                    const int v = clip_intp2(r, BD);
+                    r = v > 0 ? (v * lmcs_scale + (1 << 10)) >> 11 : -((-v * lmcs_scale + (1 << 10)) >> 11);
+                }
+                return r;
+            };
             auto add4 = [&](int i, const int4 r4) {             // w >= 4: four samples of one row per lane and step
-                int r[4] = { r4.x, r4.y, r4.z, r4.w };
+                const int r[4] = { r4.x, r4.y, r4.z, r4.w };
                 const int o = (i >> lw) * stride + (i & (w - 1));
                 int d[4];
                 dst.ld4(o, d);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (c.joint & 1)
-                        r[q] = (r[q] * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
-                    d[q] = clip_px<BD>(d[q] + r[q]);
-                }
+                for (int q = 0; q < 4; q++)
+                    d[q] = clip_px<BD>(d[q] + resid_of(r[q]));
                 dst.st4(o, d[0], d[1], d[2], d[3]);
             };
             if (w < 4) {
@@ -1755,10 +1796,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                 // predicted 4 wide, residuals added per sub-partition): one sample per lane and step, any column parity
                 for (int i = tid; i < n; i += 64) {
                     const int o = (i >> lw) * stride + (i & (w - 1));
-                    int r = gld<int>(res + i);
-                    if (c.joint & 1)
-                        r = (r * ((c.joint & 2) ? -1 : 1)) >> ((c.joint >> 2) & 1);
-                    dst.st(o, clip_px<BD>(dst.ld(o) + r));
+                    dst.st(o, clip_px<BD>(dst.ld(o) + resid_of(gld<int>(res + i))));
                 }
             } else {
 #pragma unroll

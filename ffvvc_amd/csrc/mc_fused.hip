@@ -697,7 +697,7 @@ __device__ __forceinline__ void bdof_wave(const vvc355_bipred_job *job, BipredLd
             const int vv = L.sad[(y >> 2) * sbw + (x >> 2)];
             const int vx = (int16_t)vv, vy = vv >> 16;
             const int p = (v0[i] + off + v1[i] + vx * ghd[i] + vy * gvd[i]) >> sh;
-            gst_at<px_t>(dst0, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(px_t)), (px_t)clip_px<BD>(p));
+            gst_at<px_t>(dst0, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(px_t)), (px_t)lmcs_fwd<BD>((const uint8_t *)job->lmcs_lut, clip_px<BD>(p)));
         }
     }
 }
@@ -818,6 +818,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
     // integer positions, fractions, readable rectangles (luma_mc_bi :262-283 / chroma_mc_bi :344-362, emulated_edge* :33-88)
     const int before = chroma ? 1 : 3, after = chroma ? 2 : 4;
     const int shx = 4 + (chroma ? job->hs : 0), shy = 4 + (chroma ? job->vs : 0);
+    const uint8_t *lut = chroma ? nullptr : (const uint8_t *)job->lmcs_lut;      // luma of an LMCS slice is stored through the forward map
     int ox[2], oy[2], fx[2], fy[2];
     ClampRect rc[2];
 #pragma unroll
@@ -858,7 +859,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
             if (xu >= w || y >= h)
                 continue;
             const int p = wfu ? ((v0[i] * job->w0 + rnd) >> sh) + job->o0 * (1 << (BD - 8)) : (v0[i] + rnd) >> sh;
-            gst_at<typename Px<BD>::type>(dstu, (uint32_t)(__mul24(y, job->dst_stride) + xu * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
+            gst_at<typename Px<BD>::type>(dstu, (uint32_t)(__mul24(y, job->dst_stride) + xu * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)lmcs_fwd<BD>(lut, clip_px<BD>(p)));
         }
         return;
     }
@@ -877,7 +878,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
                 continue;
             const int wg = gld<uint8_t>(wt + y * gpm->step_y + xg * gpm->step_x);
             const int p = (v0[i] * wg + v1[i] * (8 - wg) + goff) >> gsh;
-            gst_at<typename Px<BD>::type>(dstg, (uint32_t)(__mul24(y, job->dst_stride) + xg * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
+            gst_at<typename Px<BD>::type>(dstg, (uint32_t)(__mul24(y, job->dst_stride) + xg * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)lmcs_fwd<BD>(lut, clip_px<BD>(p)));
         }
         return;
     }
@@ -897,7 +898,7 @@ __device__ __forceinline__ void bipred_one(const vvc355_bipred_job *job, BipredL
         if (x >= w || y >= h)
             continue;
         const int p = wf ? (v0[i] * w0 + v1[i] * w1 + off) >> shift : (v0[i] + v1[i] + off) >> shift;
-        gst_at<typename Px<BD>::type>(dst, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)clip_px<BD>(p));
+        gst_at<typename Px<BD>::type>(dst, (uint32_t)(__mul24(y, job->dst_stride) + x * (int)sizeof(typename Px<BD>::type)), (typename Px<BD>::type)lmcs_fwd<BD>(lut, clip_px<BD>(p)));
     }
 }
 

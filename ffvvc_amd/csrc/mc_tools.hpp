@@ -407,6 +407,7 @@ __device__ __forceinline__ void bipred_tools(const vvc355_bipred_job *job, Tools
 
     uint8_t *dst = (uint8_t *)job->dst;
     const int dst_stride = job->dst_stride;
+    const uint8_t *lut = (const uint8_t *)job->lmcs_lut;        // the tools path is luma only: an LMCS slice's forward map, or 0
     uint32_t doff = (uint32_t)(__mul24(4 * by, dst_stride) + x * ISZ);
     if (!bdof) {
         int shift, off;
@@ -417,7 +418,7 @@ __device__ __forceinline__ void bipred_tools(const vvc355_bipred_job *job, Tools
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int p = wf ? (v[0][j] * w0 + v[1][j] * w1 + off) >> shift : (v[0][j] + v[1][j] + off) >> shift;
-                gst_at<px_t>(dst, doff, (px_t)clip_px<BD>(p));
+                gst_at<px_t>(dst, doff, (px_t)lmcs_fwd<BD>(lut, clip_px<BD>(p)));
                 doff += dst_stride;
             }
         }
@@ -549,7 +550,7 @@ __device__ __forceinline__ void bipred_tools(const vvc355_bipred_job *job, Tools
             const uint32_t hd = as_u32(ghd[j >> 1]), vd = as_u32(gvd[j >> 1]);
             const uint32_t g = (j & 1) ? __builtin_amdgcn_perm(vd, hd, 0x07060302u) : __builtin_amdgcn_perm(vd, hd, 0x05040100u);
             const int p = dot2(g, vxy, v[0][j] + v[1][j] + off) >> sh;
-            gst_at<px_t>(dst, doff, (px_t)clip_px<BD>(p));
+            gst_at<px_t>(dst, doff, (px_t)lmcs_fwd<BD>(lut, clip_px<BD>(p)));
             doff += dst_stride;
         }
     }

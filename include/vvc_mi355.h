@@ -459,6 +459,10 @@ typedef struct vvc355_bipred_job {
     uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
     uint8_t  pred_flag;          /* 0 or 3: bi-prediction; 1: list 0 only; 2: list 1 only (mvf->pred_flag) */
     uint8_t  pad_[5];
+    uint64_t lmcs_lut;           /* 0, or DEVICE fc->ps.lmcs.fwd_lut (1 << bd pixel-typed entries): luma blocks only — the prediction is stored
+                                  * through the forward map, which is what lmcs.filter does to an inter coding unit after predict_inter
+                                  * (vvc_inter.c:888-891, sh_lmcs_used_flag && !ciip_flag) and to the inter part of a combined inter / intra
+                                  * block before put_ciip (:573-574) */
 } vvc355_bipred_job;
 
 typedef struct vvc355_bipred_result {
@@ -523,6 +527,8 @@ typedef struct vvc355_inter_pu {
 typedef struct vvc355_inter_slice {
     uint8_t  weighted_pred, weighted_bipred;  /* IS_P && pps_weighted_pred_flag; IS_B && pps_weighted_bipred_flag */
     uint8_t  log2_denom[2];                   /* luma, chroma */
+    uint8_t  lmcs_used;                       /* sh_lmcs_used_flag: luma of the slice's inter coding units (not CIIP) goes through frame.lmcs_fwd_lut */
+    uint8_t  pad_;
     int16_t  weight[2][3][16], offset[2][3][16];      /* PredWeightTable: [list][component][ref_idx] */
 } vvc355_inter_slice;
 typedef struct vvc355_inter_frame {
@@ -539,6 +545,7 @@ typedef struct vvc355_inter_frame {
     uint8_t  hs, vs, chroma_format_idc;
     uint8_t  pixel_shift;         /* 0: 8-bit samples, 1: 16-bit samples (sps->pixel_shift) */
     uint8_t  pad_[4];
+    uint64_t lmcs_fwd_lut;        /* 0, or DEVICE fc->ps.lmcs.fwd_lut (pixel-typed, 1 << bd entries) for the slices with lmcs_used */
 } vvc355_inter_frame;
 /* job arrays only (then vvc355_bipred_batch on jobs_luma, vvc355_bipred_chroma_batch on jobs_chroma) */
 void vvc355_inter_frame_build(void *stream, const vvc355_inter_frame *frame_dev, const vvc355_inter_frame *frame_host);
@@ -568,6 +575,7 @@ typedef struct vvc355_affine_job {
     int16_t  denom, w0, w1, o0, o1;
     uint8_t  pred_flag, prof0, prof1, weight_flag;
     uint8_t  pad_[6];
+    uint64_t lmcs_lut;           /* as in vvc355_bipred_job: 0, or the forward luma map the sub-block is stored through */
 } vvc355_affine_job;
 
 void vvc355_affine_batch(void *stream, int bd, const vvc355_affine_job *jobs_dev, int n_jobs);
@@ -776,6 +784,13 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  * are added by the batched stage itself (dst != 0) before this pass; their CTUs need no commands.
  */
 enum { VVC355_RECON_MARK = 0, VVC355_RECON_PRED = 1, VVC355_RECON_CCLM = 2, VVC355_RECON_RESID = 3, VVC355_RECON_CIIP = 4 };
+/* fc->ps.lmcs as lmcs_derive_chroma_scale reads it (VVCLMCS, vvc_ps.h:193-202) */
+typedef struct vvc355_lmcs_model {
+    uint16_t pivot[17];
+    uint16_t chroma_scale_coeff[16];
+    uint8_t  min_bin_idx, max_bin_idx;
+    uint8_t  pad_[4];
+} vvc355_lmcs_model;
 typedef struct vvc355_recon_cmd {
     uint64_t resid;            /* RESID: DEVICE int32[w * h] */
     int16_t  x0, y0, w, h;
@@ -783,7 +798,12 @@ typedef struct vvc355_recon_cmd {
     int16_t  cb_width, cb_height;
     int8_t   mode;             /* cu->intra_pred_mode_y / _c as parsed (before the wide-angle mapping); CCLM: 81, 82, 83 */
     uint8_t  kind, c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag;
-    uint8_t  joint;            /* RESID: bit 0 = add_residual_joint, bit 1 = c_sign negative, bit 2 = shift */
+    uint8_t  joint;            /* RESID: bit 0 = add_residual_joint, bit 1 = c_sign negative, bit 2 = shift;
+                                * bit 3 = chroma residual scaling (itransform's chroma_scale, vvc_intra.c:449: chroma block of more than 4 samples in
+                                * a slice with sh_lmcs_used_flag and ph_chroma_residual_scale_flag): the residual — after the joint sign / shift,
+                                * vvc_intra.c:180-182 — goes through lmcs_scale_chroma (vvc_intra_template.c:431) with the scale of the 64x64
+                                * unit of (cu_x0, cu_y0), derived from the reconstructed luma left of and above that unit (:390-429) and kept
+                                * for the rest of the CTU as lc->lmcs does (reset per CTU, vvc_intra.c:509-510); needs frame.lmcs_model */
     uint8_t  pad_[6];
 } vvc355_recon_cmd;
 typedef struct vvc355_recon_ctu { uint32_t first_cmd, n_cmd; } vvc355_recon_ctu;
@@ -799,6 +819,7 @@ typedef struct vvc355_recon_frame {
     uint8_t  wpp;                 /* sps_entropy_coding_sync_enabled_flag */
     uint8_t  collocated;          /* sps_chroma_vertical_collocated_flag */
     uint8_t  pad_[3];
+    uint64_t lmcs_model;          /* 0, or DEVICE vvc355_lmcs_model: the picture's LMCS model for RESID commands with joint bit 3 (chroma residual scaling) */
 } vvc355_recon_frame;
 size_t vvc355_recon_state_bytes(int n_ctus);
 void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *frame_dev, const vvc355_recon_frame *frame_host);

@@ -401,6 +401,15 @@ static int parametric_mv_refine(const int *sad, int stride)
     return sign_num ? -quotient : quotient;
 }
 
+/* lmcs.filter (vvc_filter_template.c:25) on the luma block a job has just predicted: predict_inter does it per coding unit after every
+ * sub-block (vvc_inter.c:888-891), pred_regular_luma on the inter part of a CIIP block (:573-574); a per-sample map, so per block is the same */
+static void lmcs_block(int bd, uint64_t lut, uint64_t dst, ptrdiff_t stride, int w, int h)
+{
+    if (lut)
+        orc_lmcs_filter(bd, (uint8_t *)(uintptr_t)dst, stride, w, h, (const uint8_t *)(uintptr_t)lut);
+}
+
+
 ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
 {
     const int wide = bd > 8;
@@ -498,6 +507,8 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
                 orc_put_uni_w(bd, chroma, !!my, !!mx, udst, job->dst_stride, src, (ptrdiff_t)EMU_STRIDE << wide, h, job->denom, job->w0, job->o0, hf, vf, w);
             else
                 orc_put_uni(bd, chroma, !!my, !!mx, udst, job->dst_stride, src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
+            if (!chroma)
+                lmcs_block(bd, job->lmcs_lut, job->dst, job->dst_stride, w, h);
             return;
         }
         orc_put(bd, chroma, !!my, !!mx, tmp[i], src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
@@ -511,6 +522,8 @@ ORC_API void orc_bipred_block(int bd, const orc_bipred_job *job)
         orc_w_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h, job->denom, job->w0, job->w1, job->o0, job->o1);
     else
         orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], w, h);
+    if (!chroma)
+        lmcs_block(bd, job->lmcs_lut, job->dst, job->dst_stride, w, h);
 }
 
 
@@ -542,6 +555,8 @@ ORC_API void orc_gpm_block(int bd, const orc_gpm_job *g)
         orc_put(bd, chroma, !!my, !!mx, tmpbuf[i], src, (ptrdiff_t)EMU_STRIDE << wide, h, hf, vf, w);
     }
     orc_put_gpm(bd, (uint8_t *)(uintptr_t)job->dst, job->dst_stride, w, h, tmpbuf[0], tmpbuf[1], (const uint8_t *)(uintptr_t)g->weights, g->step_x, g->step_y);
+    if (!chroma)
+        lmcs_block(bd, job->lmcs_lut, job->dst, job->dst_stride, w, h);
 }
 
 /* ------------------------------------------------------------------ callers: one 4x4 luma sub-block of an affine CU
@@ -605,6 +620,7 @@ ORC_API void orc_affine_block(int bd, const orc_affine_job *job)
         else
             orc_avg(bd, dst, job->dst_stride, tmp[0], tmp[1], 4, 4);
     }
+    lmcs_block(bd, job->lmcs_lut, job->dst, job->dst_stride, 4, 4);
 }
 
 /* ---- pred_regular_blk over a list of coding units (vvc_inter.c:783-813): per unit the sub-block walk, the sub-block's MvField
@@ -657,6 +673,8 @@ ORC_API void orc_inter_frame_build(const orc_inter_frame *f)
                             j.bdof = !c && bi && pu->bdof_flag;
                             j.hf_idx = j.vf_idx = c ? 0 : pu->hpel_if_idx;
                             j.pred_flag = mv->pred_flag;
+                            /* predict_inter's lmcs.filter (vvc_inter.c:888-891): luma of the coding unit, not for CIIP */
+                            j.lmcs_lut = (!c && sl->lmcs_used && !pu->ciip_flag) ? f->lmcs_fwd_lut : 0;
                             if (bi) {
                                 const int weight_flag = sl->weighted_pred || (sl->weighted_bipred && !pu->dmvr_flag);
                                 if ((weight_flag || mv->bcw_idx) && !(mv->bcw_idx && pu->ciip_flag)) {

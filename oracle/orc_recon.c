@@ -100,6 +100,7 @@ typedef struct {
     int cu_x0, cu_y0;
     Area ras[2][1024];                      /* MAX_PARTS_IN_CTU, vvc_ctu.h:38 */
     int num_ras[2];
+    struct { int x_vpdu, y_vpdu, chroma_scale; } lmcs;      /* lc->lmcs: the last 64x64 unit's scale (vvc_ctu.h:406-410) */
 } Lc;
 
 /* vvc_intra.c:188-206 */
@@ -225,6 +226,7 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
             lc.ctb_up_flag = ry > 0 && !upper_tile && !upper_slice;
             lc.ctb_up_left_flag = lc.ctb_left_flag && lc.ctb_up_flag;
             lc.num_ras[0] = lc.num_ras[1] = 0;
+            lc.lmcs.x_vpdu = lc.lmcs.y_vpdu = -1;                   /* vvc_intra.c:509-510 */
             for (uint32_t k = 0; k < ctu->n_cmd; k++) {
                 const orc_recon_cmd *c = &cmds[ctu->first_cmd + k];
                 lc.cu_x0 = c->cu_x0;
@@ -287,7 +289,35 @@ ORC_API void orc_recon_frame_pass(int bd, const orc_recon_frame *f)
                     const int *res = (const int *)(uintptr_t)c->resid;
                     if (dbg_rs >= 0)
                         continue;
-                    if (c->joint & 1)
+                    if (c->joint & 8) {
+                        /* itransform with chroma_scale (:449-472) / add_residual_for_joint_coding_chroma (:179-183): the residual, after the
+                         * joint sign / shift if any, goes through lmcs_scale_chroma with the 64x64 unit's scale */
+                        static _Thread_local int tmp[64 * 64];
+                        const orc_lmcs_model *m = (const orc_lmcs_model *)(uintptr_t)f->lmcs_model;
+                        const int size_y = orc_min(ctb_size, 64);
+                        const int xv = c->cu_x0 & ~(size_y - 1), yv = c->cu_y0 & ~(size_y - 1);
+                        if (lc.lmcs.x_vpdu != xv || lc.lmcs.y_vpdu != yv) {             /* lmcs_derive_chroma_scale, vvc_intra_template.c:390-429 */
+                            orc_lmcs_scale_job sj;
+                            memset(&sj, 0, sizeof(sj));
+                            sj.luma = f->plane[0]; sj.luma_stride = f->stride[0];
+                            sj.x_vpdu = (int16_t)xv; sj.y_vpdu = (int16_t)yv; sj.pic_w = (int16_t)f->width; sj.pic_h = (int16_t)f->height; sj.size_y = (int16_t)size_y;
+                            sj.avail_t = top_available(&lc, xv, yv, 1, 0) != 0;
+                            sj.avail_l = left_available(&lc, xv, yv, 1, 0) != 0;
+                            sj.min_bin_idx = m->min_bin_idx; sj.max_bin_idx = m->max_bin_idx;
+                            memcpy(sj.pivot, m->pivot, sizeof(sj.pivot));
+                            memcpy(sj.chroma_scale_coeff, m->chroma_scale_coeff, sizeof(sj.chroma_scale_coeff));
+                            lc.lmcs.chroma_scale = orc_lmcs_chroma_scale_flat(bd, &sj);
+                            lc.lmcs.x_vpdu = xv; lc.lmcs.y_vpdu = yv;
+                        }
+                        memcpy(tmp, res, sizeof(int) * c->w * c->h);
+                        if (c->joint & 1)
+                            orc_pred_residual_joint(tmp, c->w, c->h, (c->joint & 2) ? -1 : 1, (c->joint >> 2) & 1);
+                        for (int i = 0; i < c->w * c->h; i++) {
+                            const int v = orc_clip_intp2(tmp[i], bd);
+                            tmp[i] = v > 0 ? (v * lc.lmcs.chroma_scale + (1 << 10)) >> 11 : -((-v * lc.lmcs.chroma_scale + (1 << 10)) >> 11);
+                        }
+                        orc_add_residual(bd, dst, tmp, c->w, c->h, f->stride[c_idx]);
+                    } else if (c->joint & 1)
                         orc_add_residual_joint(bd, dst, res, c->w, c->h, f->stride[c_idx], (c->joint & 2) ? -1 : 1, (c->joint >> 2) & 1);
                     else
                         orc_add_residual(bd, dst, res, c->w, c->h, f->stride[c_idx]);

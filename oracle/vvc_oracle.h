@@ -110,6 +110,7 @@ typedef struct orc_bipred_job {
     uint8_t  chroma, hs, vs, dmvr, bdof, hf_idx, vf_idx, weight_flag;
     uint8_t  pred_flag;          /* 0 or 3: bi-prediction; 1: list 0 only; 2: list 1 only (mvf->pred_flag) */
     uint8_t  pad_[5];
+    uint64_t lmcs_lut;           /* 0, or the forward luma map (lmcs.filter after predict_inter, vvc_inter.c:888-891 / on the CIIP inter part :573) */
 } orc_bipred_job;
 typedef struct orc_bipred_result {
     int32_t mv[4];
@@ -134,6 +135,7 @@ typedef struct orc_inter_pu {
 } orc_inter_pu;
 typedef struct orc_inter_slice {
     uint8_t  weighted_pred, weighted_bipred, log2_denom[2];
+    uint8_t  lmcs_used, pad_;
     int16_t  weight[2][3][16], offset[2][3][16];
 } orc_inter_slice;
 typedef struct orc_inter_frame {
@@ -146,6 +148,7 @@ typedef struct orc_inter_frame {
     int32_t  n_pus, n_jobs;
     int32_t  width, height;
     uint8_t  hs, vs, chroma_format_idc, pixel_shift, pad_[4];
+    uint64_t lmcs_fwd_lut;
 } orc_inter_frame;
 void orc_inter_frame_build(const orc_inter_frame *f);
 void orc_inter_frame_pass(int bd, const orc_inter_frame *f);
@@ -160,6 +163,7 @@ typedef struct orc_affine_job {
     int16_t  denom, w0, w1, o0, o1;
     uint8_t  pred_flag, prof0, prof1, weight_flag;
     uint8_t  pad_[6];
+    uint64_t lmcs_lut;
 } orc_affine_job;
 void orc_affine_block(int bd, const orc_affine_job *job);
 
@@ -343,7 +347,14 @@ typedef struct orc_recon_frame {
     int32_t  stride[3];
     int32_t  width, height, ctb_width, ctb_height, n_work;
     uint8_t  ctb_log2, hs, vs, wpp, collocated, pad_[3];
+    uint64_t lmcs_model;          /* 0, or orc_lmcs_model for RESID commands with joint bit 3 */
 } orc_recon_frame;
+typedef struct orc_lmcs_model {
+    uint16_t pivot[17];
+    uint16_t chroma_scale_coeff[16];
+    uint8_t  min_bin_idx, max_bin_idx;
+    uint8_t  pad_[4];
+} orc_lmcs_model;
 void orc_recon_frame_pass(int bd, const orc_recon_frame *f);
 void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_intra_job *out);
 

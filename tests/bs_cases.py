@@ -22,6 +22,10 @@ def _split(rng, x, y, w, h, pw, ph, min_size, out, p_big=0.75, p_small=0.35):
         kind = int(rng.integers(0, 3))
         if must and not inside:
             kind = 0 if can_q else (1 if x + w > pw else 2)
+        elif w > 64 and h <= 64:
+            kind = 1        # VVC keeps every 64x64 pipeline unit contiguous in coding order: a block wider than 64 and at most 64 tall
+        elif h > 64 and w <= 64:
+            kind = 2        # only splits vertically, and the other way round (no 128x32 / 32x128 blocks)
         if kind == 0 and can_q:
             for dy in (0, h // 2):
                 for dx in (0, w // 2):

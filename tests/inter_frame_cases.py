@@ -74,8 +74,10 @@ class InterWork:
         counts = np.array([n_jobs_of(p["cb_width"], p["cb_height"], p["num_sb_x"], p["num_sb_y"]) for p in self.pus], np.int64)
         self.pus["first_job"] = np.concatenate(([0], np.cumsum(counts)[:-1]))
         self.n_jobs = int(counts.sum())
-        # slice 0: default weighting; slice 1: explicit weighted bi-prediction and weighted uni-prediction
+        # slice 0: default weighting, LMCS on (sh_lmcs_used_flag: the luma of its inter units, CIIP excepted, goes through the forward map);
+        # slice 1: explicit weighted bi-prediction and weighted uni-prediction, no LMCS
         self.slices = (abi.InterSlice * 2)()
+        self.slices[0].lmcs_used = 1
         s1 = self.slices[1]
         s1.weighted_pred, s1.weighted_bipred = 0, 1
         s1.log2_denom[0], s1.log2_denom[1] = 6, 5
@@ -85,13 +87,14 @@ class InterWork:
                     s1.weight[l][c][r] = int(rng.integers(-32, 96))
                     s1.offset[l][c][r] = int(rng.integers(-20, 21))
 
-    def frame(self, dst_ptrs, dst_strides, mvf_ptr, refs_ptr, pus_ptr, slices_ptr, jl_ptr, jc_ptr, rec_ptr, hs, vs, isz, dmvr_ptr=0):
+    def frame(self, dst_ptrs, dst_strides, mvf_ptr, refs_ptr, pus_ptr, slices_ptr, jl_ptr, jc_ptr, rec_ptr, hs, vs, isz, dmvr_ptr=0, lut_ptr=0):
         f = abi.InterFrame()
         for c in range(3):
             f.dst[c], f.dst_stride[c] = dst_ptrs[c], dst_strides[c]
         f.mvf, f.refs, f.pus, f.slices = mvf_ptr, refs_ptr, pus_ptr, slices_ptr
         f.jobs_luma, f.jobs_chroma, f.records = jl_ptr, jc_ptr, rec_ptr
         f.dmvr_mvf = dmvr_ptr
+        f.lmcs_fwd_lut = lut_ptr
         f.mvf_stride, f.n_pus, f.n_jobs = self.width // 4, len(self.pus), self.n_jobs
         f.width, f.height = self.width, self.height
         f.hs, f.vs, f.chroma_format_idc, f.pixel_shift = hs, vs, 1, int(isz == 2)

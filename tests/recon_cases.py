@@ -16,7 +16,7 @@ class ReconWork:
     cmds["resid"] as ELEMENT offsets until `bind(base_address)` turns them into addresses."""
 
     def __init__(self, rng, width, height, ctb_log2=7, hs=1, vs=1, intra_frac=1.0, intra_ctu=None, cclm_frac=0.2, coded_p=0.7,
-                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True, ciip_frac=0.0, ciip_ctu=None, isp_p=0.15):
+                 n_slices=1, tiles=False, min_cu=8, split=(0.85, 0.45), tools=True, ciip_frac=0.0, ciip_ctu=None, isp_p=0.15, lmcs=False, resid_ctu=None):
         self.width, self.height, self.ctb_log2, self.hs, self.vs = width, height, ctb_log2, hs, vs
         ctb = 1 << ctb_log2
         self.ncx, self.ncy = (width + ctb - 1) // ctb, (height + ctb - 1) // ctb
@@ -37,6 +37,7 @@ class ReconWork:
         self.ciip_len = 0
         self.ciip_frac = ciip_frac
         self.isp_p = isp_p
+        self.lmcs = lmcs                  # chroma residual scaling on (sh_lmcs_used_flag && ph_chroma_residual_scale_flag): RESID bit 3 on chroma blocks of more than 4 samples
         for rs in range(n_ctb):
             rx, ry = rs % self.ncx, rs // self.ncx
             first = len(cmds)
@@ -48,6 +49,7 @@ class ReconWork:
             else:
                 _split(rng, rx * ctb, ry * ctb, ctb, ctb, width, height, min_cu, leaves, *split)
             any_intra = False
+            inter_resid = False
             cu_cmds = []
             for (x, y, w, h) in leaves:
                 if whole_ciip or rng.random() >= ctu_intra and self.ciip_frac and w * h >= 64 and w < 128 and h < 128 and rng.random() < self.ciip_frac:
@@ -68,13 +70,21 @@ class ReconWork:
                     cu_cmds.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, *cu))
                     continue
                 if rng.random() >= ctu_intra:
-                    # not intra-coded: prediction and residual come from the batched stages, the walk only records the area
+                    # not intra-coded: prediction and residual come from the batched stages, the walk only records the area — unless the
+                    # chroma residuals of this CTU's inter units are left to the walk (resid_ctu): with chroma residual scaling they depend
+                    # on the reconstructed luma around their 64x64 unit, which may be an intra CTU's (itransform runs for every coding unit
+                    # in the reference's RECON stage, vvc_intra.c:480-496)
                     cu_cmds.append(self._cmd(abi.RECON_MARK, 0, x, y, w, h, x, y, w, h))
                     cu_cmds.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, x, y, w, h))
+                    if resid_ctu is not None and resid_ctu[rs] and (w >> self.hs) >= 4 and rng.random() < coded_p:
+                        cwc, chc = w >> self.hs, h >> self.vs
+                        for c in (1, 2):
+                            cu_cmds.append(self._cmd(abi.RECON_RESID, c, x, y, cwc, chc, x, y, w, h, resid=self._resid(c, x, y, cwc, chc), joint=8 if (lmcs and cwc * chc > 4) else 0))
+                        inter_resid = True
                     continue
                 any_intra = True
                 self._intra_cu(rng, cu_cmds, x, y, w, h, ctb, cclm_frac, coded_p, tools)
-            if any_intra:
+            if any_intra or inter_resid:
                 cmds += cu_cmds
                 ctus[rs]["first_cmd"], ctus[rs]["n_cmd"] = first, len(cu_cmds)
         self.cmds = np.array(cmds, CMD) if cmds else np.zeros(0, CMD)
@@ -133,12 +143,13 @@ class ReconWork:
                 out.append(self._cmd(abi.RECON_PRED, c, x, y, w, h, *cu, mode=cmode, bdpcm_flag=0))
         out.append(self._cmd(abi.RECON_MARK, 1, x, y, w, h, *cu))
         joint = tools and rng.random() < 0.15
+        sc = 8 if (self.lmcs and cw * chh > 4) else 0        # itransform's chroma_scale (vvc_intra.c:449)
         for c in (1, 2):
             if rng.random() < coded_p:
-                out.append(self._cmd(abi.RECON_RESID, c, x, y, cw, chh, *cu, resid=self._resid(c, x, y, cw, chh)))
+                out.append(self._cmd(abi.RECON_RESID, c, x, y, cw, chh, *cu, resid=self._resid(c, x, y, cw, chh), joint=sc))
                 if joint and c == 1:
                     # add_residual_for_joint_coding_chroma (:166-186): the same residual goes to the other component, signed / halved
-                    out.append(self._cmd(abi.RECON_RESID, 2, x, y, cw, chh, *cu, resid=out[-1][0], joint=1 | (2 * int(rng.integers(0, 2))) | (4 * int(rng.integers(0, 2)))))
+                    out.append(self._cmd(abi.RECON_RESID, 2, x, y, cw, chh, *cu, resid=out[-1][0], joint=sc | 1 | (2 * int(rng.integers(0, 2))) | (4 * int(rng.integers(0, 2)))))
                     break
 
     def bind(self, base, ciip_base=0, isz=2):
@@ -151,7 +162,19 @@ class ReconWork:
         c["resid"][is_ci] = ciip_base + c["resid"][is_ci] * isz
         return c
 
-    def frame(self, planes, strides, cmds_ptr, ctus_ptr, order_ptr, state_ptr, slice_ptr, col_ptr, row_ptr, wpp=0, collocated=0):
+    @staticmethod
+    def lmcs_model(rng, bd):
+        """An LMCS model as lmcs_derive_chroma_scale reads it: 16 bins with increasing pivots, a chroma scale per bin (11-bit fixed point around 1.0)."""
+        m = abi.LmcsModel()
+        cuts = np.sort(rng.choice(np.arange(1, 1 << bd), size=15, replace=False))
+        for i, v in enumerate([0] + [int(v) for v in cuts] + [1 << bd]):
+            m.pivot[i] = min(v, 65535)
+        for i in range(16):
+            m.chroma_scale_coeff[i] = int(rng.integers(1024, 4096))
+        m.min_bin_idx, m.max_bin_idx = int(rng.integers(0, 3)), int(rng.integers(12, 16))
+        return m
+
+    def frame(self, planes, strides, cmds_ptr, ctus_ptr, order_ptr, state_ptr, slice_ptr, col_ptr, row_ptr, wpp=0, collocated=0, lmcs_ptr=0):
         f = abi.ReconFrame()
         for c in range(3):
             f.plane[c], f.stride[c] = planes[c], strides[c]
@@ -159,4 +182,5 @@ class ReconWork:
         f.slice_idx, f.ctb_to_col_bd, f.ctb_to_row_bd = slice_ptr, col_ptr, row_ptr
         f.width, f.height, f.ctb_width, f.ctb_height, f.n_work = self.width, self.height, self.ncx, self.ncy, len(self.order)
         f.ctb_log2, f.hs, f.vs, f.wpp, f.collocated = self.ctb_log2, self.hs, self.vs, wpp, collocated
+        f.lmcs_model = lmcs_ptr
         return f

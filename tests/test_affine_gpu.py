@@ -25,6 +25,8 @@ def test_affine_frame(dev, orc, bd):
     n = (pw // 4) * (ph // 4)
     dmv = rng.integers(-32, 33, size=(n, 2, 2, 16)).astype(np.int16)          # [job][list][x | y][16]
     d_dmv = batch.DeviceBuffer.from_host(dmv)
+    lut = np.sort(np.random.default_rng(0x10C5 + bd).integers(0, 1 << bd, size=1 << bd)).astype(refs[0].dtype)          # LMCS forward map on a third of the sub-blocks
+    d_lut = batch.DeviceBuffer.from_host(lut)
     arr = (abi.AffineJob * n)()
     kinds = set()
     for i in range(n):
@@ -47,7 +49,9 @@ def test_affine_frame(dev, orc, bd):
         hj = abi.AffineJob.from_buffer_copy(j)
         hj.dst, hj.ref0, hj.ref1 = P(want, y * pw + x), P(refs[0]), P(refs[1])
         hj.diff_mv = P(dmv, i * 64)
+        hj.lmcs_lut = P(lut) if i % 3 == 0 else 0
         orc.orc_affine_block(bd, ctypes.byref(hj))
+        j.lmcs_lut = d_lut.ptr if i % 3 == 0 else 0
         j.dst, j.ref0, j.ref1 = d_out.ptr + (y * pw + x) * isz, d_refs[0].ptr, d_refs[1].ptr
         j.diff_mv = d_dmv.ptr + i * 128
         arr[i] = j

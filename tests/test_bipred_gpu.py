@@ -38,6 +38,9 @@ def test_bipred_frame(dev, orc, bd, fmt):
     d_rec = batch.DeviceBuffer.from_host(np.zeros(n * 32, np.uint8))
     luma = (abi.BipredJob * n)()
     chroma = (abi.BipredJob * (2 * n))()
+    # LMCS: a third of the luma blocks are stored through a forward map (lmcs.filter after predict_inter, vvc_inter.c:888-891)
+    lut = np.sort(np.random.default_rng(0x10C5 + bd).integers(0, 1 << bd, size=1 << bd)).astype(base[0].dtype)
+    d_lut = batch.DeviceBuffer.from_host(lut)
     host_jobs = []
     for i, (x, y, w, h) in enumerate(blocks):
         kind = i % 5
@@ -91,6 +94,7 @@ def test_bipred_frame(dev, orc, bd, fmt):
         hj.dst = P(want[c], hj.y * dims[c][0] + hj.x)
         hj.ref0, hj.ref1 = P(refs[0][c]), P(refs[1][c])
         hj.rec = ctypes.addressof(want_rec[i])
+        hj.lmcs_lut = P(lut) if (c == 0 and i % 3 == 0) else 0
         orc.orc_bipred_block(bd, ctypes.byref(hj))
 
     # ---- device: all luma jobs in one launch, then all chroma jobs
@@ -100,6 +104,7 @@ def test_bipred_frame(dev, orc, bd, fmt):
         dj.dst = d_out[c].ptr + (dj.y * dims[c][0] + dj.x) * isz
         dj.ref0, dj.ref1 = d_refs[0][c].ptr, d_refs[1][c].ptr
         dj.rec = d_rec.ptr + 32 * i
+        dj.lmcs_lut = d_lut.ptr if (c == 0 and i % 3 == 0) else 0
         if c == 0:
             luma[nl] = dj; nl += 1
         else:
@@ -160,6 +165,8 @@ def test_gpm_batch(dev, orc, bd, fmt):
     d_out = [batch.DeviceBuffer.from_host(w_) for w_ in want]
     d_refs = [[batch.DeviceBuffer.from_host(p) for p in r] for r in refs]
     d_mask = batch.DeviceBuffer.from_host(mask)
+    lut = np.sort(np.random.default_rng(0x10C5 + bd).integers(0, 1 << bd, size=1 << bd)).astype(refs[0][0].dtype)       # LMCS forward map on every other luma block
+    d_lut = batch.DeviceBuffer.from_host(lut)
     jobs = []
     for y in range(0, ph - 15, 16):
         for x in range(0, pw - 15, 16):
@@ -192,7 +199,9 @@ def test_gpm_batch(dev, orc, bd, fmt):
         hg.base.dst = P(want[c], hg.base.y * dims[c][0] + hg.base.x)
         hg.base.ref0, hg.base.ref1 = P(refs[0][c]), P(refs[1][c])
         hg.weights = mask.ctypes.data + first
+        hg.base.lmcs_lut = P(lut) if (c == 0 and (i // 3) % 2 == 0) else 0
         orc.orc_gpm_block(bd, ctypes.byref(hg))
+        g.base.lmcs_lut = d_lut.ptr if (c == 0 and (i // 3) % 2 == 0) else 0
         g.base.dst = d_out[c].ptr + (g.base.y * dims[c][0] + g.base.x) * isz
         g.base.ref0, g.base.ref1 = d_refs[0][c].ptr, d_refs[1][c].ptr
         g.weights = d_mask.ptr + first

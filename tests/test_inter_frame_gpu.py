@@ -11,7 +11,7 @@ import inter_frame_cases as ifc
 from ffvvc_amd import abi, batch
 
 pytestmark = pytest.mark.gpu
-ADDR = ("dst", "ref0", "ref1", "rec", "dst_stride", "ref0_stride", "ref1_stride")       # host planes are packed, device planes pitched
+ADDR = ("dst", "ref0", "ref1", "rec", "dst_stride", "ref0_stride", "ref1_stride", "lmcs_lut")       # host planes are packed, device planes pitched
 
 
 def ref_table(ptrs, strides):
@@ -37,6 +37,8 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h, mv_range):
     base = [bc.smooth_picture(rng, ph, pw, bd) for (pw, ph) in dims]
     refs = [[[bc.shifted(base[c], (2 * l - 1) * (r + 1) >> (hs if c else 0), (1 - 2 * l) * (r + 2) >> (vs if c else 0)) for c in range(3)] for r in range(2)] for l in range(2)]
     jl_dt = batch.job_array(abi.BipredJob, 1).dtype
+    lut = np.sort(np.random.default_rng(0x10C5 + bd).integers(0, 1 << bd, size=1 << bd)).astype(base[0].dtype)          # fc->ps.lmcs.fwd_lut
+    d_lut = batch.DeviceBuffer.from_host(lut)
 
     # ---- oracle on host memory
     want = [np.zeros((ph, pw), base[0].dtype) for (pw, ph) in dims]
@@ -46,7 +48,7 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h, mv_range):
     h_refs = ref_table([[[refs[l][r][c].ctypes.data for c in range(3)] for r in range(2)] for l in range(2)],
                        [[[refs[l][r][c].shape[1] * isz for c in range(3)] for r in range(2)] for l in range(2)])
     hf = work.frame([p.ctypes.data for p in want], [d[0] * isz for d in dims], work.mvf.ctypes.data, ctypes.addressof(h_refs), work.pus.ctypes.data,
-                    ctypes.addressof(work.slices), h_jl.ctypes.data, h_jc.ctypes.data, h_rec.ctypes.data, hs, vs, isz, dmvr_ptr=h_dmvr.ctypes.data)
+                    ctypes.addressof(work.slices), h_jl.ctypes.data, h_jc.ctypes.data, h_rec.ctypes.data, hs, vs, isz, dmvr_ptr=h_dmvr.ctypes.data, lut_ptr=lut.ctypes.data)
     orc.orc_inter_frame_pass(bd, ctypes.byref(hf))
 
     # ---- device
@@ -60,7 +62,7 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h, mv_range):
     d_sl = batch.DeviceBuffer.from_host(np.frombuffer(bytes(work.slices), np.uint8))
     d_jl, d_jc, d_rec = batch.DeviceBuffer(h_jl.nbytes), batch.DeviceBuffer(h_jc.nbytes), batch.DeviceBuffer(h_rec.nbytes)
     d_dmvr = batch.DeviceBuffer.from_host(work.mvf.view(np.uint8))
-    df = work.frame([b.ptr for b in d_dst], pitches, d_mvf.ptr, d_reft.ptr, d_pus.ptr, d_sl.ptr, d_jl.ptr, d_jc.ptr, d_rec.ptr, hs, vs, isz, dmvr_ptr=d_dmvr.ptr)
+    df = work.frame([b.ptr for b in d_dst], pitches, d_mvf.ptr, d_reft.ptr, d_pus.ptr, d_sl.ptr, d_jl.ptr, d_jc.ptr, d_rec.ptr, hs, vs, isz, dmvr_ptr=d_dmvr.ptr, lut_ptr=d_lut.ptr)
     d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
     dev.vvc355_inter_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df))
     dev.vvc355_stream_sync(None)
@@ -85,6 +87,12 @@ def test_inter_frame_pass(dev, orc, bd, fmt, w, h, mv_range):
                 assert (got[key + "_stride"][used] == pitches[c]).all() and (got[key][~used & m] == 0).all()
             assert np.array_equal(exp["dst"][m] - want[c].ctypes.data, ey * dims[c][0] * isz + ex * isz)
         assert np.array_equal((got["rec"] - d_rec.ptr) // 32, (exp["rec"] - h_rec.ctypes.data) // 32)
+        # the forward map: on the luma jobs of slice 0's units that are not CIIP, nowhere else
+        assert np.array_equal(got["lmcs_lut"] != 0, exp["lmcs_lut"] != 0) and set(np.unique(got["lmcs_lut"])) <= {0, d_lut.ptr}
+        if comps[0] == 0:
+            assert (exp["lmcs_lut"] != 0).any() and (exp["lmcs_lut"] == 0).any()
+        else:
+            assert (exp["lmcs_lut"] == 0).all()
         kinds |= {(int(p), int(d), int(b), int(wf)) for p, d, b, wf in zip(exp["pred_flag"], exp["dmvr"], exp["bdof"], exp["weight_flag"])}
     # the case mix: uni / bi, DMVR, BDOF, default / bcw / explicit weights all occur
     if w * h >= 128 * 128:

@@ -21,6 +21,8 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
     hs, vs = fmt
     isz = 1 if bd == 8 else 2
     work = recon_cases.ReconWork(rng, w, h, ctb_log2, hs, vs, **kw)
+    model = recon_cases.ReconWork.lmcs_model(np.random.default_rng(0x1A5C + bd), bd) if kw.get("lmcs") else None
+    d_model = batch.DeviceBuffer.from_host(np.frombuffer(bytes(model), np.uint8)) if model is not None else None
     dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
     planes = [bc.smooth_picture(rng, ph, pw, bd, scale=16) for (pw, ph) in dims]
     resid = rng.integers(-(1 << (bd - 3)), 1 << (bd - 3), size=max(1, work.resid_len)).astype(np.int32)
@@ -29,7 +31,8 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
     want = [p.copy() for p in planes]
     hc = work.bind(resid.ctypes.data, inter.ctypes.data, isz)
     hf = work.frame([P(p) for p in want], [d[0] * isz for d in dims], hc.ctypes.data, work.ctus.ctypes.data, work.order.ctypes.data, 0,
-                    work.slice_idx.ctypes.data, work.col_bd.ctypes.data, work.row_bd.ctypes.data, wpp=kw.get("n_slices", 1) > 2, collocated=int(rng.integers(0, 2)))
+                    work.slice_idx.ctypes.data, work.col_bd.ctypes.data, work.row_bd.ctypes.data, wpp=kw.get("n_slices", 1) > 2, collocated=int(rng.integers(0, 2)),
+                    lmcs_ptr=ctypes.addressof(model) if model is not None else 0)
     orc.orc_recon_frame_pass(bd, ctypes.byref(hf))
     # device
     pitched = [batch.to_pitched(p) for p in planes]
@@ -40,7 +43,7 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
     d_state = batch.DeviceBuffer(dev.vvc355_recon_state_bytes(work.ncx * work.ncy))
     d_slice, d_col, d_row = batch.DeviceBuffer.from_host(work.slice_idx), batch.DeviceBuffer.from_host(work.col_bd), batch.DeviceBuffer.from_host(work.row_bd)
     df = work.frame([b.ptr for b in d_planes], [p.shape[1] * isz for p in pitched], d_cmds.ptr, d_ctus.ptr, d_order.ptr, d_state.ptr,
-                    d_slice.ptr, d_col.ptr, d_row.ptr, wpp=hf.wpp, collocated=hf.collocated)
+                    d_slice.ptr, d_col.ptr, d_row.ptr, wpp=hf.wpp, collocated=hf.collocated, lmcs_ptr=d_model.ptr if d_model is not None else 0)
     d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
     for rep in range(2):           # twice: the second pass must find its scheduling state reset (and reproduce the result from the same start)
         for b, p in zip(d_planes, pitched):
@@ -100,3 +103,17 @@ def test_recon_vertical_isp_narrow_transform_blocks(dev, orc, bd, fmt, min_cu):
     assert (luma["w"] == 2).sum() > 8
     if min_cu == 4:
         assert (luma["w"] == 1).sum() >= 4 and ((luma["w"] == 1) & (luma["x0"] % 2 == 1)).sum() >= 2
+
+
+@pytest.mark.parametrize("bd,fmt,ctb_log2", [(10, (1, 1), 7), (8, (1, 1), 6), (12, (0, 0), 5), (10, (1, 0), 6)])
+def test_recon_lmcs_chroma_residual_scaling(dev, orc, bd, fmt, ctb_log2):
+    """Chroma residual scaling (sh_lmcs_used_flag && ph_chroma_residual_scale_flag): every chroma residual of more than 4 samples is
+    scaled by the factor of its coding unit's 64x64 unit — derived in the walk from the reconstructed luma left of and above that unit
+    (lmcs_derive_chroma_scale, vvc_intra_template.c:390-429; kept per unit, reset per CTU) — including joint Cb-Cr blocks (sign / shift first,
+    vvc_intra.c:180-182), across slices and tiles, at picture edges, and for the inter coding units of CTUs whose chroma residuals the walk adds."""
+    rng = np.random.default_rng(0x5EED0EB0 + bd + ctb_log2)
+    n_ctb = ((456 + (1 << ctb_log2) - 1) >> ctb_log2) * ((264 + (1 << ctb_log2) - 1) >> ctb_log2)
+    work, changed = run_case(dev, orc, rng, bd, 456, 264, ctb_log2, fmt, intra_frac=0.6, n_slices=3 if ctb_log2 < 7 else 1, tiles=ctb_log2 == 6, lmcs=True,
+                             resid_ctu=np.ones(n_ctb, bool))
+    res = work.cmds[work.cmds["kind"] == abi.RECON_RESID]
+    assert ((res["joint"] & 8) != 0).sum() > 100 and ((res["joint"] & 9) == 9).sum() > 3 and ((res["joint"] & 8) == 0).sum() > 50
