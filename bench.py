@@ -44,6 +44,7 @@ DEBLOCK_JOBS = False           # deblocking through the stage driver (edge param
 AFFINE_FRAC = 0.06             # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF on both lists); --affine-frac
 GPM_FRAC = 0.05                # fraction of the regular inter blocks coded as geometric partitions (two uni-predictions + mask blend)
 CIIP_FRAC = 0.02               # fraction of the CTUs whose coding units are combined inter / intra (inter prediction aside, planar intra + blend in RECON)
+LMCS = True                    # sh_lmcs_used_flag + ph_chroma_residual_scale_flag on: forward luma map on the inter prediction, chroma residual scaling (--no-lmcs)
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 CTB = 128
@@ -164,6 +165,8 @@ def alf_filter_sets(rng, n_sets):
 
 def build_chain(lib, torch, fr):
     """Build every stage's job descriptors once (host side, numpy) and return the list of Stage objects."""
+    if os.path.join(ROOT, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
     rng = np.random.default_rng(0x5EED0001)
     bd, isz = fr.bd, fr.isz
     ptr = lambda t: t.data_ptr()          # noqa: E731
@@ -191,6 +194,22 @@ def build_chain(lib, torch, fr):
     # CTU kinds: 80 % inter, 20 % intra; of the inter CTUs a few are affine and a few combined inter / intra (CIIP)
     ctu_inter = rng.random(fr.n_ctus) < INTER_FRAC
     ctu_ciip = ctu_inter & (rng.random(fr.n_ctus) < CIIP_FRAC / max(INTER_FRAC, 1e-9))
+    # LMCS (own generator: the other draws stay what they were): the forward luma map of the inter prediction and the model of the chroma
+    # residual scaling.  The scale of a 64x64 unit comes from the reconstructed luma left of and above it, so the chroma residuals of an
+    # inter CTU whose left or upper neighbour is reconstructed by the in-order pass (intra, CIIP) are added by that pass, behind the
+    # neighbour; the other inter CTUs' chroma residuals are scaled in one batched launch before it.
+    rng_l = np.random.default_rng(0x5EED0ECF)
+    px_np = np.uint8 if bd == 8 else np.uint16
+    d_fwd = fr.upload(np.sort(rng_l.integers(0, 1 << bd, size=1 << bd)).astype(px_np)) if LMCS else None
+    fwd_ptr = ptr(d_fwd) if LMCS else 0
+    import recon_cases as _rc
+    lmcs_model = _rc.ReconWork.lmcs_model(rng_l, bd) if LMCS else None
+    d_model = fr.upload(np.frombuffer(bytes(lmcs_model), np.uint8)) if LMCS else None
+    in_order = (~ctu_inter | ctu_ciip).reshape(fr.ncy, fr.ncx)              # CTUs whose luma the in-order pass writes
+    nb = np.zeros_like(in_order)
+    nb[:, 1:] |= in_order[:, :-1]
+    nb[1:, :] |= in_order[:-1, :]
+    ctu_dep = (ctu_inter & ~ctu_ciip & nb.reshape(-1)) if LMCS else np.zeros(fr.n_ctus, bool)
 
     # ---------------------------------------------------------------- inter prediction: regular bi-predicted 16x16 luma sub-blocks
     # with DMVR and BDOF switched on (search, parametric refinement, 8-tap MC at the refined motion, BDOF), then their 8x8
@@ -238,6 +257,7 @@ def build_chain(lib, torch, fr):
             j["chroma"], j["hs"], j["vs"] = int(c > 0), 1, 1
             j["dmvr"], j["bdof"] = MC_TOOLS & 1, ((MC_TOOLS >> 1) & 1) if c == 0 else 0
             j["pred_flag"] = 3
+            j["lmcs_lut"] = fwd_ptr if c == 0 else 0
             bj.append(j)
         # chroma jobs interleaved Cb, Cr, Cb, Cr, ...: the chroma launch predicts the two planes of a sub-block in one wave
         luma_jobs = bj[0]
@@ -266,7 +286,9 @@ def build_chain(lib, torch, fr):
                 reft[l * 16].plane[c] = ref_org(l, c)
                 reft[l * 16].stride[c] = ref_pitch(l, c)
         d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
-        d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(abi.InterSlice()), np.uint8))
+        islice = abi.InterSlice()
+        islice.lmcs_used = int(LMCS)
+        d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(islice), np.uint8))
         d_bl = torch.zeros(luma_jobs.nbytes, dtype=torch.uint8, device="cuda")
         d_bc = torch.zeros(chroma_jobs.nbytes, dtype=torch.uint8, device="cuda")
         fr.keep += [d_bl, d_bc]
@@ -278,6 +300,7 @@ def build_chain(lib, torch, fr):
         inf.mvf_stride, inf.n_pus, inf.n_jobs = pic_w // 4, n_blk, n_blk
         inf.width, inf.height = pic_w, pic_h
         inf.hs, inf.vs, inf.chroma_format_idc, inf.pixel_shift = 1, 1, 1, int(isz == 2)
+        inf.lmcs_fwd_lut = fwd_ptr
         d_inf = fr.upload(np.frombuffer(bytes(inf), np.uint8))
         fr.keep.append(inf)
 
@@ -336,6 +359,7 @@ def build_chain(lib, torch, fr):
             b["mv"] = gmv
             b["x"], b["y"], b["w"], b["h"], b["pic_w"], b["pic_h"] = xg0 >> sh, yg0 >> sh, 16 >> sh, 16 >> sh, w, h
             b["chroma"], b["hs"], b["vs"] = int(c > 0), 1, 1
+            b["lmcs_lut"] = fwd_ptr if c == 0 else 0
             first = goff[:, 1] * 112 + goff[:, 0]
             j["step_x"], j["step_y"] = 1 << sh, 112 << sh
             m1, m2 = gmir == 1, gmir == 2
@@ -363,6 +387,7 @@ def build_chain(lib, torch, fr):
                 blk = np.zeros((g.base.h, g.base.w), dt)
                 g.base.dst, g.base.dst_stride = blk.ctypes.data, g.base.w * isz
                 g.base.ref0, g.base.ref1 = env.mirror.host_addr(g.base.ref0), env.mirror.host_addr(g.base.ref1)
+                g.base.lmcs_lut = env.mirror.host_addr(g.base.lmcs_lut) if g.base.lmcs_lut else 0
                 g.weights = env.mirror.host_addr(g.weights)
                 orc.orc_gpm_block(bd, ctypes.byref(g))
                 bad += not np.array_equal(env.after[rec_ptrs[c]][y_:y_ + g.base.h, x_:x_ + g.base.w], blk)
@@ -389,6 +414,7 @@ def build_chain(lib, torch, fr):
         afj["mv"] = base_mv + rng.integers(-8, 9, size=(n_sb, 4))
         afj["x"], afj["y"], afj["pic_w"], afj["pic_h"] = ax, ay, fr.width, fr.height
         afj["pred_flag"], afj["prof0"], afj["prof1"] = 3, 1, 1
+        afj["lmcs_lut"] = fwd_ptr
         acj = []
         for c in (1, 2):
             j = batch.job_array(abi.BipredJob, len(xa0))
@@ -426,6 +452,7 @@ def build_chain(lib, torch, fr):
                 x_, y_ = (off % pitches[0]) // isz, off // pitches[0]
                 j.dst, j.dst_stride = blk.ctypes.data, 4 * isz
                 j.ref0, j.ref1, j.diff_mv = env.mirror.host_addr(j.ref0), env.mirror.host_addr(j.ref1), env.mirror.host_addr(j.diff_mv)
+                j.lmcs_lut = env.mirror.host_addr(j.lmcs_lut) if j.lmcs_lut else 0
                 orc.orc_affine_block(bd, ctypes.byref(j))
                 bad += not np.array_equal(env.after[rec_ptrs[0]][y_:y_ + 4, x_:x_ + 4], blk)
             cidx = np.nonzero(np.isin(np.repeat((ya0 // CTB) * fr.ncx + xa0 // CTB, 2), env.picks))[0]
@@ -440,7 +467,8 @@ def build_chain(lib, torch, fr):
     # the residual adds through the in-order wavefront pass further down
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import recon_cases
-    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1), ciip_ctu=ctu_ciip)
+    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1), ciip_ctu=ctu_ciip,
+                                 lmcs=LMCS, resid_ctu=ctu_dep if LMCS else None)
 
     # the inter half of the CIIP coding units: plain bi-prediction (CIIP switches DMVR / BDOF off) of every 16x16 (chroma 8x8 or 16x16)
     # tile into packed per-CU blocks that the RECON pass blends with the planar intra prediction
@@ -469,6 +497,7 @@ def build_chain(lib, torch, fr):
         cjobs["x"], cjobs["y"], cjobs["w"], cjobs["h"] = cj[:, 1], cj[:, 2], cj[:, 3], cj[:, 4]
         cjobs["pic_w"], cjobs["pic_h"] = np.array([d[0] for d in fr.dims])[cc], np.array([d[1] for d in fr.dims])[cc]
         cjobs["chroma"], cjobs["hs"], cjobs["vs"] = (cc > 0).astype(np.int64), 1, 1
+        cjobs["lmcs_lut"] = np.where(cc == 0, fwd_ptr, 0)          # the inter part of a CIIP block is mapped before the blend (vvc_inter.c:573-574)
         cl, cch = cjobs[cc == 0], cjobs[cc > 0]
         d_cl, d_cch = fr.upload(cl.view(np.uint8)), fr.upload(cch.view(np.uint8))
         n_cl, n_cch = len(cl), len(cch)
@@ -488,6 +517,7 @@ def build_chain(lib, torch, fr):
                 first, pitch_px = (int(j.dst) - ptr(d_ciip)) // isz, j.dst_stride // isz
                 j.dst, j.dst_stride = blk.ctypes.data, j.w * isz
                 j.ref0, j.ref1 = env.mirror.host_addr(j.ref0), env.mirror.host_addr(j.ref1)
+                j.lmcs_lut = env.mirror.host_addr(j.lmcs_lut) if j.lmcs_lut else 0
                 orc.orc_bipred_block(bd, ctypes.byref(j))
                 rows = np.stack([got[first + r * pitch_px:first + r * pitch_px + j.w] for r in range(j.h)])
                 bad += not np.array_equal(rows, blk)
@@ -500,7 +530,11 @@ def build_chain(lib, torch, fr):
     windows = []               # (first coefficient, block size, nzw[], nzh[]) of every group of blocks laid out back to back
     ctu_by_shape = {}
     coeff_off = 0
+    chroma_first = None        # with LMCS: first coefficient (int32 index) of the chroma blocks, whose residuals stay in the buffer for the scaling stage
+    cres = []                  # (component, x0, y0, size, first coefficient byte offset) per group of chroma blocks
     for c, (w, h) in enumerate(fr.dims):
+        if c == 1 and LMCS:
+            chroma_first = coeff_off // 4
         if c == 0:
             # per 128x128 CTU: one 64x64, four 32x32, sixteen 16x16, sixty-four 8x8 (one size per quadrant)
             parts = [(0, 0, 64), (64, 0, 32), (0, 64, 16), (64, 64, 8)]
@@ -515,6 +549,8 @@ def build_chain(lib, torch, fr):
             y0 = (cy0[:, None] + qy + oy.ravel()[None, :]).ravel()
             kc = (y0 // cs) * fr.ncx + (x0 // cs)
             keep = ctu_inter[kc] & ~ctu_ciip[kc]       # the intra CTUs have their own transform blocks (below); the CIIP coding units carry no residual here
+            if c and LMCS:
+                keep &= ~ctu_dep[kc]                   # their chroma residuals are scaled and added by the in-order pass (RESID commands of `work`)
             x0, y0 = x0[keep], y0[keep]
             if not len(x0):
                 continue
@@ -534,6 +570,10 @@ def build_chain(lib, torch, fr):
             j["nzw"] = 1 + (rng.random(len(x0)) * lim_h).astype(np.int64)
             j["nzh"] = 1 + (rng.random(len(x0)) * lim_v).astype(np.int64)
             j["range"], j["bd"], j["store_coeffs"] = 15, bd, 0
+            if c and LMCS:
+                # chroma residual scaling: the transform leaves the residual in the buffer, the scaling stage adds it
+                j["dst"], j["store_coeffs"] = 0, 1
+                cres.append((c, x0.copy(), y0.copy(), n, j["coeffs"].copy()))
             by_shape.setdefault(lg, []).append(j)
             ctu_by_shape.setdefault(lg, []).append((y0 // cs) * fr.ncx + (x0 // cs))
             windows.append((int(j["coeffs"][0]) // 4, n, j["nzw"].copy(), j["nzh"].copy()))
@@ -572,17 +612,74 @@ def build_chain(lib, torch, fr):
         itx_all["log2_matrix_size"], itx_all["dc"] = 1, -1
         d_itx = fr.upload(itx_all.view(np.uint8))
 
+        scaled = LMCS and chroma_first is not None and chroma_first < n_samples
+        if scaled:
+            coeffs_c = coeffs[chroma_first:]                 # the chroma blocks' part: levels in, residuals out (restored from the pristine copy every step)
+            coeffs_c0 = coeffs_c.clone()
+            fr.keep += [coeffs_c, coeffs_c0]
+
         def launch_itx(st):
+            if scaled:
+                lib.vvc355_copy_async(st, coeffs_c.data_ptr(), coeffs_c0.data_ptr(), coeffs_c.numel() * 4)
             for (first, count, lg) in itx_launches:
                 lib.vvc355_itx_shape_batch(st, bd, ptr(d_itx) + first * jsz, count, lg, lg)
 
         def check_itx(fc, orc, env):
-            env.mirror.add(coeffs.data_ptr(), env.snap(coeffs))
+            levels = env.snap(coeffs)
+            if scaled:
+                levels[chroma_first:] = env.snap(coeffs_c0)
+            env.mirror.add(coeffs.data_ptr(), levels)
             idx = np.nonzero(np.isin(ctu_of_itx, env.picks))[0]
-            bad = fc.check_itx(orc, bd, itx_all, idx, env.mirror, [env.before[p_] for p_ in rec_ptrs], [env.after[p_] for p_ in rec_ptrs], rec_ptrs, pitches)
+            bad = fc.check_itx(orc, bd, itx_all, idx, env.mirror, [env.before[p_] for p_ in rec_ptrs], [env.after[p_] for p_ in rec_ptrs], rec_ptrs, pitches,
+                               coeffs_after=(coeffs_c.data_ptr(), env.after[coeffs_c.data_ptr()]) if scaled else None)
             return len(idx), bad
 
-        chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz), writes=rec, check=check_itx))
+        chain.append(Stage("dequant_itx_add_residual", f"itx_shape_kernel<{bd}, *>", launch_itx, n_samples * (4 + 2 * isz), writes=rec + ([coeffs_c] if scaled else []), check=check_itx))
+
+        if scaled:
+            # ---------------------------------------------------------------- chroma residual scaling of the inter CTUs that do not depend on the in-order
+            # pass: per block the 64x64 unit's scale from the reconstructed luma (prediction + residual: final for these CTUs), then
+            # lmcs_scale_chroma + add_residual
+            rjs = []
+            for (c, x0c, y0c, n, cofs) in cres:
+                rj = batch.job_array(abi.LmcsResidJob, len(x0c))
+                rj["dst"] = ptr(rec[c]) + y0c * fr.pitch(rec[c]) + x0c * isz
+                rj["dst_stride"], rj["luma"], rj["luma_stride"] = fr.pitch(rec[c]), ptr(rec[0]), fr.pitch(rec[0])
+                rj["resid"] = cofs + coeffs.data_ptr()
+                rj["w"] = rj["h"] = n
+                rj["x_vpdu"], rj["y_vpdu"] = (2 * x0c) & ~63, (2 * y0c) & ~63
+                rj["pic_w"], rj["pic_h"], rj["size_y"] = fr.width, fr.height, 64
+                rj["avail_l"], rj["avail_t"] = rj["x_vpdu"] > 0, rj["y_vpdu"] > 0          # one slice, one tile: every neighbour inside the picture exists
+                rj["joint"] = 8
+                rjs.append(rj)
+            rj_all = np.concatenate(rjs)
+            ctu_of_rj = np.concatenate([((2 * y0c) // CTB) * fr.ncx + (2 * x0c) // CTB for (_c, x0c, y0c, _n, _o) in cres])
+            d_rj = fr.upload(rj_all.view(np.uint8))
+            n_rj = len(rj_all)
+
+            def check_lmcs_resid(fc, orc, env):
+                orc.orc_lmcs_chroma_resid_block.argtypes = [ctypes.c_int, ctypes.POINTER(abi.LmcsResidJob), ctypes.POINTER(abi.LmcsModel)]
+                orc.orc_lmcs_chroma_resid_block.restype = None
+                idx = np.nonzero(np.isin(ctu_of_rj, env.picks))[0]
+                luma_h, res_h = env.snap(rec[0]), env.snap(coeffs_c)
+                dt = np.uint8 if bd == 8 else np.uint16
+                bad = 0
+                for i in idx:
+                    j = abi.LmcsResidJob.from_buffer_copy(rj_all[i].tobytes())
+                    c = next(k for k in (1, 2) if rec_ptrs[k] <= j.dst < rec_ptrs[k] + env.after[rec_ptrs[k]].nbytes)
+                    off = int(j.dst) - rec_ptrs[c]
+                    x_, y_ = (off % pitches[c]) // isz, off // pitches[c]
+                    blk = np.ascontiguousarray(env.before[rec_ptrs[c]][y_:y_ + j.h, x_:x_ + j.w]).astype(dt)
+                    r = np.ascontiguousarray(res_h[(int(j.resid) - coeffs_c.data_ptr()) // 4:][:j.w * j.h])
+                    j.dst, j.dst_stride, j.resid, j.luma = blk.ctypes.data, j.w * isz, r.ctypes.data, luma_h.ctypes.data
+                    orc.orc_lmcs_chroma_resid_block(bd, ctypes.byref(j), ctypes.byref(lmcs_model))
+                    bad += not np.array_equal(env.after[rec_ptrs[c]][y_:y_ + j.h, x_:x_ + j.w], blk)
+                return len(idx), bad
+
+            n_cs = int(sum(len(x0c) * n * n for (_c, x0c, _y, n, _o) in cres))
+            chain.append(Stage("lmcs_chroma_residual_scale", f"lmcs_chroma_resid_kernel<{bd}>",
+                               lambda st: lib.vvc355_lmcs_chroma_resid_batch(st, bd, ptr(d_rj), n_rj, ptr(d_model)),
+                               n_cs * (4 + 2 * isz), writes=[rec[1], rec[2]], check=check_lmcs_resid))
 
     # ---------------------------------------------------------------- transform blocks of the intra CTUs: scaling process (+ LFNST on a
     # fifth of the luma blocks) + inverse transform with the transform types derived on the device (implicit MTS), residuals left
@@ -676,7 +773,8 @@ def build_chain(lib, torch, fr):
         d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(work.order)
         d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8))
         d_rslice, d_rcol, d_rrow = fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)
-        rf = work.frame(rec_ptrs, pitches, ptr(d_cmds), ptr(d_ctus), ptr(d_order), ptr(d_rstate), ptr(d_rslice), ptr(d_rcol), ptr(d_rrow))
+        rf = work.frame(rec_ptrs, pitches, ptr(d_cmds), ptr(d_ctus), ptr(d_order), ptr(d_rstate), ptr(d_rslice), ptr(d_rcol), ptr(d_rrow),
+                        lmcs_ptr=ptr(d_model) if LMCS else 0)
         d_rf = fr.upload(np.frombuffer(bytes(rf), np.uint8))
         fr.keep.append(rf)
         n_pred = int((work.cmds["kind"] == abi.RECON_PRED).sum() + (work.cmds["kind"] == abi.RECON_CCLM).sum())
@@ -693,7 +791,7 @@ def build_chain(lib, torch, fr):
             env.mirror.add(ptr(d_ciip), env.snap(d_ciip))
             hc = work.bind(env.mirror.host_addr(ptr(res)), env.mirror.host_addr(ptr(d_ciip)), isz)
             env.mirror.add(ptr(d_cmds), hc.view(np.uint8))
-            f = fc.translate(rf, env.mirror, ("plane", "cmds", "ctus", "order", "slice_idx", "ctb_to_col_bd", "ctb_to_row_bd"))
+            f = fc.translate(rf, env.mirror, ("plane", "cmds", "ctus", "order", "slice_idx", "ctb_to_col_bd", "ctb_to_row_bd") + (("lmcs_model",) if LMCS else ()))
             f.state = 0
             orc.orc_recon_frame_pass(bd, ctypes.byref(f))
             bad = sum(int(not np.array_equal(w_, env.after[p_])) for p_, w_ in zip(rec_ptrs, work_p))
@@ -1409,6 +1507,7 @@ def parse_args(argv=None):
     ap.add_argument("--with-upload", action="store_true", help="additionally time the steps with every per-frame descriptor copied from pinned host memory first")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
+    ap.add_argument("--no-lmcs", action="store_true", help="profiling aid: a picture without LMCS (no forward map on the inter prediction, no chroma residual scaling)")
     ap.add_argument("--noise", action="store_true", help="profiling aid: uniformly random reference samples and dense residuals (checkasm-style) "
                                                          "instead of picture-like content: every DMVR search runs to the end, deblocking mostly early-outs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough wall-clock budget of the CPU baseline leg (one core first, then all cores)")
@@ -1442,7 +1541,8 @@ def main(argv=None):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 2 * max(1, args.frames_in_flight))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
-    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES, INTER_FRAC
+    global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES, INTER_FRAC, LMCS
+    LMCS = not args.no_lmcs
     INTER_FRAC = args.inter_frac
     SAO_TABLES = not args.sao_jobs
     ALF_TABLES = not args.alf_jobs

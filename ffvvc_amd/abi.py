@@ -119,6 +119,7 @@ BATCH_SIGNATURES = {
     "dequant_batch":    ("v", "ppi"),
     "intra_pred_batch": ("v", "pipii"),
     "cclm_batch":       ("v", "pipi"),
+    "lmcs_chroma_resid_batch": ("v", "pipip"),
     "pred_fused_batch": ("v", "pipi"),
     "bipred_batch":     ("v", "pipi"),
     "bipred_chroma_batch": ("v", "pipi"),
@@ -486,6 +487,17 @@ class LmcsScaleJob(ctypes.Structure):
         ("size_y", ctypes.c_int16),
         ("avail_t", ctypes.c_uint8), ("avail_l", ctypes.c_uint8), ("min_bin_idx", ctypes.c_uint8), ("max_bin_idx", ctypes.c_uint8),
         ("pivot", ctypes.c_uint16 * 17), ("chroma_scale_coeff", ctypes.c_uint16 * 16), ("pad_", ctypes.c_uint16 * 6),
+    ]
+
+
+class LmcsResidJob(ctypes.Structure):
+    """Mirror of vvc355_lmcs_resid_job / orc_lmcs_resid_job."""
+    _fields_ = [
+        ("dst", ctypes.c_uint64), ("resid", ctypes.c_uint64), ("luma", ctypes.c_uint64),
+        ("dst_stride", ctypes.c_int32), ("luma_stride", ctypes.c_int32),
+        ("w", ctypes.c_int16), ("h", ctypes.c_int16), ("x_vpdu", ctypes.c_int16), ("y_vpdu", ctypes.c_int16),
+        ("pic_w", ctypes.c_int16), ("pic_h", ctypes.c_int16), ("size_y", ctypes.c_int16),
+        ("avail_l", ctypes.c_uint8), ("avail_t", ctypes.c_uint8), ("joint", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 7),
     ]
 
 

@@ -1170,9 +1170,79 @@ __global__ __launch_bounds__(256) void lmcs_scale_kernel(const vvc355_lmcs_scale
     }
 }
 
+// One wave per chroma block: the 64x64 unit's scale from the luma plane (lanes 0 .. size_y - 1 fetch one left and one upper neighbour
+// each, lmcs_sum_samples' replication beyond the picture = a clamped index), then the residual — joint sign / shift, lmcs_scale_chroma —
+// added to the block, four samples of a row per lane and step (one at a time for blocks narrower than four).
+template <int BD>
+__global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmcs_resid_job *__restrict__ jobs, int n_jobs, const vvc355_lmcs_model *__restrict__ model)
+{
+    using px_t = typename Px<BD>::type;
+    const int ji = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ji >= n_jobs)
+        return;
+    const vvc355_lmcs_resid_job j = load_uniform(jobs + ji);
+    int scale = 0;
+    if (j.joint & 8) {
+        const uint8_t *luma = (const uint8_t *)j.luma;
+        const int ls = j.luma_stride / (int)sizeof(px_t), size = j.size_y, x = j.x_vpdu, y = j.y_vpdu;
+        int v = 0;
+        if (lane < size) {
+            if (j.avail_l)
+                v += ld_px<BD>(luma, (ptrdiff_t)(y + min(lane, min(j.pic_h - y, size) - 1)) * ls + x - 1);
+            if (j.avail_t)
+                v += ld_px<BD>(luma, (ptrdiff_t)(y - 1) * ls + x + min(lane, min(j.pic_w - x, size) - 1));
+        }
+#pragma unroll
+        for (int sft = 32; sft; sft >>= 1)
+            v += __shfl_xor(v, sft, 64);
+        const int cnt = (j.avail_l ? size : 0) + (j.avail_t ? size : 0);
+        const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
+        int bin = gld<uint8_t>(&model->min_bin_idx);
+        const int last = gld<uint8_t>(&model->max_bin_idx);
+        while (bin <= last && avg >= (int)gld<uint16_t>(&model->pivot[bin + 1]))
+            bin++;
+        scale = __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&model->chroma_scale_coeff[min(bin, 15)]));
+    }
+    auto resid_of = [&](int r) {
+        if (j.joint & 1)
+            r = (r * ((j.joint & 2) ? -1 : 1)) >> ((j.joint >> 2) & 1);
+        if (j.joint & 8) {
+            const int c = clip_intp2(r, BD);
+            r = c > 0 ? (c * scale + (1 << 10)) >> 11 : -((-c * scale + (1 << 10)) >> 11);
+        }
+        return r;
+    };
+    const int w = j.w, n = w * j.h, lw = ilog2i(w);
+    const int *res = (const int *)j.resid;
+    uint8_t *dst = (uint8_t *)j.dst;
+    if (w < 4) {
+        for (int i = lane; i < n; i += 64) {
+            uint8_t *row = dst + row_off(i >> lw, j.dst_stride);
+            st_px<BD>(row, i & (w - 1), clip_px<BD>(ld_px<BD>(row, i & (w - 1)) + resid_of(gld<int>(res + i))));
+        }
+        return;
+    }
+    for (int i = lane * 4; i < n; i += 256) {
+        const int4 r4 = gld<int4>(res + i);
+        uint8_t *row = dst + row_off(i >> lw, j.dst_stride);
+        const int xo = i & (w - 1);
+        const int r[4] = { r4.x, r4.y, r4.z, r4.w };
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            st_px<BD>(row, xo + q, clip_px<BD>(ld_px<BD>(row, xo + q) + resid_of(r[q])));
+    }
+}
+
 } // namespace vvc355
 
 extern "C" {
+
+void vvc355_lmcs_chroma_resid_batch(void *stream, int bd, const vvc355_lmcs_resid_job *jobs_dev, int n_jobs, const vvc355_lmcs_model *model_dev)
+{
+    if (n_jobs <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((vvc355::lmcs_chroma_resid_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs, model_dev));
+    HIP_CHECK(hipGetLastError());
+}
 
 void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, int n_jobs)
 {

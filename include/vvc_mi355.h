@@ -403,6 +403,38 @@ typedef struct vvc355_lmcs_scale_job {
 } vvc355_lmcs_scale_job;
 
 void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, int n_jobs);
+
+/* fc->ps.lmcs as lmcs_derive_chroma_scale reads it (VVCLMCS, vvc_ps.h:193-202) */
+typedef struct vvc355_lmcs_model {
+    uint16_t pivot[17];
+    uint16_t chroma_scale_coeff[16];
+    uint8_t  min_bin_idx, max_bin_idx;
+    uint8_t  pad_[4];
+} vvc355_lmcs_model;
+
+/*
+ * Chroma residual scaling outside the in-order pass: one chroma transform block whose residual (already inverse-transformed, e.g. by
+ * vvc355_itx_batch with store_coeffs) is scaled and added to the picture — the tail of itransform (vvc_intra.c:449-472) and
+ * add_residual_for_joint_coding_chroma (:166-186) with chroma_scale set.  The scale is the one lmcs_derive_chroma_scale
+ * (vvc_intra_template.c:390-429) gives for the 64x64 unit of the coding unit, derived per job from the reconstructed luma plane.
+ * Valid wherever the luma left of and above that unit is final when the launch runs — e.g. the inter coding units of CTUs whose left,
+ * upper and upper-left neighbour CTUs are not reconstructed by the in-order pass; every other block takes the RESID command of
+ * vvc355_recon_frame_pass (joint bit 3), which orders it.
+ *   x_vpdu, y_vpdu   (cu->x0, cu->y0) & ~(size_y - 1), luma samples; size_y = min(CtbSizeY, 64); pic_w, pic_h luma picture size
+ *   avail_l/_t       ff_vvc_get_left_available / _top_available(lc, x_vpdu, y_vpdu, 1, 0) != 0 (picture, slice, tile borders)
+ *   joint            as vvc355_recon_cmd.joint (bit 0 joint residual, bit 1 negative sign, bit 2 shift; bit 3 = scale, 0 = plain add)
+ */
+typedef struct vvc355_lmcs_resid_job {
+    uint64_t dst;                 /* DEVICE: the block in its chroma plane */
+    uint64_t resid;               /* DEVICE int32[w * h] */
+    uint64_t luma;                /* DEVICE: sample (0, 0) of the luma plane */
+    int32_t  dst_stride, luma_stride;      /* bytes */
+    int16_t  w, h;                /* chroma samples */
+    int16_t  x_vpdu, y_vpdu, pic_w, pic_h, size_y;
+    uint8_t  avail_l, avail_t, joint;
+    uint8_t  pad_[7];
+} vvc355_lmcs_resid_job;
+void vvc355_lmcs_chroma_resid_batch(void *stream, int bd, const vvc355_lmcs_resid_job *jobs_dev, int n_jobs, const vvc355_lmcs_model *model_dev);
 /* synchronous forms: plane addresses are HOST addresses; pic_w/pic_h (luma samples) bound what is staged */
 void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h);
 void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height);
@@ -784,13 +816,6 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  * are added by the batched stage itself (dst != 0) before this pass; their CTUs need no commands.
  */
 enum { VVC355_RECON_MARK = 0, VVC355_RECON_PRED = 1, VVC355_RECON_CCLM = 2, VVC355_RECON_RESID = 3, VVC355_RECON_CIIP = 4 };
-/* fc->ps.lmcs as lmcs_derive_chroma_scale reads it (VVCLMCS, vvc_ps.h:193-202) */
-typedef struct vvc355_lmcs_model {
-    uint16_t pivot[17];
-    uint16_t chroma_scale_coeff[16];
-    uint8_t  min_bin_idx, max_bin_idx;
-    uint8_t  pad_[4];
-} vvc355_lmcs_model;
 typedef struct vvc355_recon_cmd {
     uint64_t resid;            /* RESID: DEVICE int32[w * h] */
     int16_t  x0, y0, w, h;

@@ -335,3 +335,33 @@ ORC_API void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_in
     orc_recon_frame_pass(10, f);
     dbg_rs = dbg_k = -1;
 }
+
+/* The tail of itransform with chroma_scale (vvc_intra.c:449-472; joint blocks :179-183) for one chroma block outside the walk: the scale
+ * of the coding unit's 64x64 unit from the luma plane as it stands (lmcs_derive_chroma_scale, vvc_intra_template.c:390-429), then
+ * pred_residual_joint (if joint), lmcs_scale_chroma, add_residual. */
+ORC_API void orc_lmcs_chroma_resid_block(int bd, const orc_lmcs_resid_job *j, const orc_lmcs_model *m)
+{
+    static _Thread_local int tmp[64 * 64];
+    const int n = j->w * j->h;
+    const int *res = (const int *)(uintptr_t)j->resid;
+    uint8_t *dst = (uint8_t *)(uintptr_t)j->dst;
+    memcpy(tmp, res, sizeof(int) * n);
+    if (j->joint & 1)
+        orc_pred_residual_joint(tmp, j->w, j->h, (j->joint & 2) ? -1 : 1, (j->joint >> 2) & 1);
+    if (j->joint & 8) {
+        orc_lmcs_scale_job sj;
+        memset(&sj, 0, sizeof(sj));
+        sj.luma = j->luma; sj.luma_stride = j->luma_stride;
+        sj.x_vpdu = j->x_vpdu; sj.y_vpdu = j->y_vpdu; sj.pic_w = j->pic_w; sj.pic_h = j->pic_h; sj.size_y = j->size_y;
+        sj.avail_t = j->avail_t; sj.avail_l = j->avail_l;
+        sj.min_bin_idx = m->min_bin_idx; sj.max_bin_idx = m->max_bin_idx;
+        memcpy(sj.pivot, m->pivot, sizeof(sj.pivot));
+        memcpy(sj.chroma_scale_coeff, m->chroma_scale_coeff, sizeof(sj.chroma_scale_coeff));
+        const int scale = orc_lmcs_chroma_scale_flat(bd, &sj);
+        for (int i = 0; i < n; i++) {
+            const int v = orc_clip_intp2(tmp[i], bd);
+            tmp[i] = v > 0 ? (v * scale + (1 << 10)) >> 11 : -((-v * scale + (1 << 10)) >> 11);
+        }
+    }
+    orc_add_residual(bd, dst, tmp, j->w, j->h, j->dst_stride);
+}

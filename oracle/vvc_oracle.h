@@ -356,6 +356,14 @@ typedef struct orc_lmcs_model {
     uint8_t  pad_[4];
 } orc_lmcs_model;
 void orc_recon_frame_pass(int bd, const orc_recon_frame *f);
+/* same layout as vvc355_lmcs_resid_job: one chroma block's residual scaled (lmcs_scale_chroma) and added outside the in-order walk */
+typedef struct orc_lmcs_resid_job {
+    uint64_t dst, resid, luma;
+    int32_t  dst_stride, luma_stride;
+    int16_t  w, h, x_vpdu, y_vpdu, pic_w, pic_h, size_y;
+    uint8_t  avail_l, avail_t, joint, pad_[7];
+} orc_lmcs_resid_job;
+void orc_lmcs_chroma_resid_block(int bd, const orc_lmcs_resid_job *job, const orc_lmcs_model *model);
 void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_intra_job *out);
 
 #ifdef __cplusplus

@@ -88,6 +88,7 @@ def check_bipred(orc, bd, jobs, idx, mirror, planes_after, plane_ptrs, pitches, 
                     rec.mv[m] = int(dev_rec[m])
         j.dst, j.dst_stride = blk.ctypes.data, j.w * isz
         j.ref0, j.ref1 = mirror.host_addr(j.ref0), mirror.host_addr(j.ref1)
+        j.lmcs_lut = mirror.host_addr(j.lmcs_lut) if j.lmcs_lut else 0
         j.rec = ctypes.addressof(rec) if dev_rec is not None else 0
         orc.orc_bipred_block(bd, ctypes.byref(j))
         got = planes_after[c][y:y + j.h, x:x + j.w]
@@ -100,8 +101,9 @@ def check_bipred(orc, bd, jobs, idx, mirror, planes_after, plane_ptrs, pitches, 
     return bad
 
 
-def check_itx(orc, bd, jobs, idx, mirror, before, after, plane_ptrs, pitches):
-    """dequant (fused scaling process) + inverse transform + residual add of the transform blocks in `idx`."""
+def check_itx(orc, bd, jobs, idx, mirror, before, after, plane_ptrs, pitches, coeffs_after=None):
+    """dequant (fused scaling process) + inverse transform + residual add of the transform blocks in `idx`; blocks without a
+    destination (store_coeffs: the residual stays in the buffer) are compared in coeffs_after = (device address, array)."""
     isz = 1 if bd == 8 else 2
     bad = 0
     for i in idx:
@@ -109,8 +111,9 @@ def check_itx(orc, bd, jobs, idx, mirror, before, after, plane_ptrs, pitches):
         lw, lh = int(j["log2_w"]), int(j["log2_h"])
         w, h = 1 << lw, 1 << lh
         dst = int(j["dst"])
-        c = next(k for k, p in enumerate(plane_ptrs) if p <= dst < p + before[k].nbytes)
-        x, y = _plane_xy(dst, plane_ptrs[c], pitches[c], isz)
+        if dst:
+            c = next(k for k, p in enumerate(plane_ptrs) if p <= dst < p + before[k].nbytes)
+            x, y = _plane_xy(dst, plane_ptrs[c], pitches[c], isz)
         src = np.ctypeslib.as_array((ctypes.c_int32 * (w * h)).from_address(mirror.host_addr(int(j["coeffs"]))))
         co = np.ascontiguousarray(src).copy()
         nzw, nzh, rng_, qp = int(j["nzw"]), int(j["nzh"]), int(j["range"]), int(j["dq_qp"])
@@ -119,6 +122,10 @@ def check_itx(orc, bd, jobs, idx, mirror, before, after, plane_ptrs, pitches):
             orc.orc_dequant(co.ctypes.data, lw, lh, 0, 0, nzw - 1, nzh - 1, qp, 0, (int(j["dq_flags"]) >> 1) & 1, bd, rng_, sm,
                             int(j["log2_matrix_size"]), int(j["dc"]))
         orc.orc_itx(int(j["trh"]), int(j["trv"]), lw, lh, co.ctypes.data, nzw, nzh, rng_, int(j["bd"]))
+        if not dst:
+            first = (int(j["coeffs"]) - coeffs_after[0]) // 4
+            bad += not np.array_equal(coeffs_after[1][first:first + w * h], co)
+            continue
         blk = np.ascontiguousarray(before[c][y:y + h, x:x + w])
         orc.orc_add_residual(bd, blk.ctypes.data, co.ctypes.data, w, h, w * isz)
         if not np.array_equal(after[c][y:y + h, x:x + w], blk):
