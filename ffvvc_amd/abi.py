@@ -263,7 +263,7 @@ class ReconCmd(ctypes.Structure):
 
 class ReconCtu(ctypes.Structure):
     """Mirror of vvc355_recon_ctu."""
-    _fields_ = [("first_cmd", ctypes.c_uint32), ("n_cmd", ctypes.c_uint32)]
+    _fields_ = [("first_cmd", ctypes.c_uint32), ("n_cmd", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
 
 
 class ReconFrame(ctypes.Structure):
@@ -285,6 +285,7 @@ class LmcsModel(ctypes.Structure):
 
 
 RECON_MARK, RECON_PRED, RECON_CCLM, RECON_RESID, RECON_CIIP = 0, 1, 2, 3, 4
+RECON_CTU_LIGHT, RECON_CTU_LUMA_LEFT, RECON_CTU_LUMA_UP = 1, 2, 4
 TU_MTS_ENABLED, TU_EXPLICIT_MTS_INTRA, TU_ISP, TU_SBT, TU_SBT_HORIZONTAL, TU_SBT_POS, TU_INTRA, TU_MIP = 1, 2, 4, 8, 16, 32, 64, 128
 ITX_DERIVE_TYPE = 1
 

@@ -1170,9 +1170,65 @@ __global__ __launch_bounds__(256) void lmcs_scale_kernel(const vvc355_lmcs_scale
     }
 }
 
-// One wave per chroma block: the 64x64 unit's scale from the luma plane (lanes 0 .. size_y - 1 fetch one left and one upper neighbour
-// each, lmcs_sum_samples' replication beyond the picture = a clamped index), then the residual — joint sign / shift, lmcs_scale_chroma —
-// added to the block, four samples of a row per lane and step (one at a time for blocks narrower than four).
+// lmcs_derive_chroma_scale (vvc_intra_template.c:390-429) of the 64x64 unit at (x, y) from a luma plane in HBM, one wave: lanes
+// 0 .. size - 1 fetch one left and one upper neighbour each (lmcs_sum_samples' replication beyond the picture = a clamped index)
+template <int BD>
+__device__ __forceinline__ int lmcs_scale_from_plane(const vvc355_lmcs_model *model, const uint8_t *luma, int ls, int x, int y, int size, bool avail_l, bool avail_t,
+                                                     int pic_w, int pic_h, int lane)
+{
+    int v = 0;
+    if (lane < size) {
+        if (avail_l)
+            v += ld_px<BD>(luma, (ptrdiff_t)(y + min(lane, min(pic_h - y, size) - 1)) * ls + x - 1);
+        if (avail_t)
+            v += ld_px<BD>(luma, (ptrdiff_t)(y - 1) * ls + x + min(lane, min(pic_w - x, size) - 1));
+    }
+#pragma unroll
+    for (int sft = 32; sft; sft >>= 1)
+        v += __shfl_xor(v, sft, 64);
+    const int cnt = (avail_l ? size : 0) + (avail_t ? size : 0);
+    const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
+    int bin = gld<uint8_t>(&model->min_bin_idx);
+    const int last = gld<uint8_t>(&model->max_bin_idx);
+    while (bin <= last && avg >= (int)gld<uint16_t>(&model->pivot[bin + 1]))
+        bin++;
+    return __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&model->chroma_scale_coeff[min(bin, 15)]));
+}
+
+// the tail of itransform for one block in HBM, one wave: joint sign / shift (pred_residual_joint), lmcs_scale_chroma when joint bit 3 is
+// set, add_residual; four samples of a row per lane and step (one at a time for blocks narrower than four)
+template <int BD>
+__device__ __forceinline__ void resid_block_add(uint8_t *dst, int dst_stride, const int *res, int w, int h, int joint, int scale, int lane)
+{
+    auto resid_of = [&](int r) {
+        if (joint & 1)
+            r = (r * ((joint & 2) ? -1 : 1)) >> ((joint >> 2) & 1);
+        if (joint & 8) {
+            const int c = clip_intp2(r, BD);
+            r = c > 0 ? (c * scale + (1 << 10)) >> 11 : -((-c * scale + (1 << 10)) >> 11);
+        }
+        return r;
+    };
+    const int n = w * h, lw = ilog2i(w);
+    if (w < 4) {
+        for (int i = lane; i < n; i += 64) {
+            uint8_t *row = dst + row_off(i >> lw, dst_stride);
+            st_px<BD>(row, i & (w - 1), clip_px<BD>(ld_px<BD>(row, i & (w - 1)) + resid_of(gld<int>(res + i))));
+        }
+        return;
+    }
+    for (int i = lane * 4; i < n; i += 256) {
+        const int4 r4 = gld<int4>(res + i);
+        uint8_t *row = dst + row_off(i >> lw, dst_stride);
+        const int xo = i & (w - 1);
+        const int r[4] = { r4.x, r4.y, r4.z, r4.w };
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            st_px<BD>(row, xo + q, clip_px<BD>(ld_px<BD>(row, xo + q) + resid_of(r[q])));
+    }
+}
+
+// One wave per chroma block: the 64x64 unit's scale from the luma plane, then the residual added to the block.
 template <int BD>
 __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmcs_resid_job *__restrict__ jobs, int n_jobs, const vvc355_lmcs_model *__restrict__ model)
 {
@@ -1181,56 +1237,9 @@ __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmc
     if (ji >= n_jobs)
         return;
     const vvc355_lmcs_resid_job j = load_uniform(jobs + ji);
-    int scale = 0;
-    if (j.joint & 8) {
-        const uint8_t *luma = (const uint8_t *)j.luma;
-        const int ls = j.luma_stride / (int)sizeof(px_t), size = j.size_y, x = j.x_vpdu, y = j.y_vpdu;
-        int v = 0;
-        if (lane < size) {
-            if (j.avail_l)
-                v += ld_px<BD>(luma, (ptrdiff_t)(y + min(lane, min(j.pic_h - y, size) - 1)) * ls + x - 1);
-            if (j.avail_t)
-                v += ld_px<BD>(luma, (ptrdiff_t)(y - 1) * ls + x + min(lane, min(j.pic_w - x, size) - 1));
-        }
-#pragma unroll
-        for (int sft = 32; sft; sft >>= 1)
-            v += __shfl_xor(v, sft, 64);
-        const int cnt = (j.avail_l ? size : 0) + (j.avail_t ? size : 0);
-        const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
-        int bin = gld<uint8_t>(&model->min_bin_idx);
-        const int last = gld<uint8_t>(&model->max_bin_idx);
-        while (bin <= last && avg >= (int)gld<uint16_t>(&model->pivot[bin + 1]))
-            bin++;
-        scale = __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&model->chroma_scale_coeff[min(bin, 15)]));
-    }
-    auto resid_of = [&](int r) {
-        if (j.joint & 1)
-            r = (r * ((j.joint & 2) ? -1 : 1)) >> ((j.joint >> 2) & 1);
-        if (j.joint & 8) {
-            const int c = clip_intp2(r, BD);
-            r = c > 0 ? (c * scale + (1 << 10)) >> 11 : -((-c * scale + (1 << 10)) >> 11);
-        }
-        return r;
-    };
-    const int w = j.w, n = w * j.h, lw = ilog2i(w);
-    const int *res = (const int *)j.resid;
-    uint8_t *dst = (uint8_t *)j.dst;
-    if (w < 4) {
-        for (int i = lane; i < n; i += 64) {
-            uint8_t *row = dst + row_off(i >> lw, j.dst_stride);
-            st_px<BD>(row, i & (w - 1), clip_px<BD>(ld_px<BD>(row, i & (w - 1)) + resid_of(gld<int>(res + i))));
-        }
-        return;
-    }
-    for (int i = lane * 4; i < n; i += 256) {
-        const int4 r4 = gld<int4>(res + i);
-        uint8_t *row = dst + row_off(i >> lw, j.dst_stride);
-        const int xo = i & (w - 1);
-        const int r[4] = { r4.x, r4.y, r4.z, r4.w };
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            st_px<BD>(row, xo + q, clip_px<BD>(ld_px<BD>(row, xo + q) + resid_of(r[q])));
-    }
+    const int scale = (j.joint & 8) ? lmcs_scale_from_plane<BD>(model, (const uint8_t *)j.luma, j.luma_stride / (int)sizeof(px_t), j.x_vpdu, j.y_vpdu, j.size_y,
+                                                                j.avail_l != 0, j.avail_t != 0, j.pic_w, j.pic_h, lane) : 0;
+    resid_block_add<BD>((uint8_t *)j.dst, j.dst_stride, (const int *)j.resid, j.w, j.h, j.joint, scale, lane);
 }
 
 } // namespace vvc355
@@ -1409,7 +1418,7 @@ __device__ __forceinline__ void recon_luma_done_set(ReconLds &L, int v)
 __device__ __forceinline__ int recon_luma_done_get(ReconLds &L)
 {
     return __hip_atomic_load((VVC355_LDS int *)&L.luma_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done
+}        // state[0] = ticket counter, state[kReconFlags + rs] = CTU rs done, state[kReconFlags + n_ctus + rs] = its luma is in the planes
 
 // one wave per CTU and channel type: a CTU's blocks are a dependent chain (each reads what the previous ones wrote), so more lanes
 // per block would only add workgroup barriers to every link.  TILE (4:2:0, CTUs up to 128x128): the CTU's three component blocks live in LDS for the whole
@@ -1535,6 +1544,60 @@ __device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane
     }
 }
 
+// A LIGHT CTU (vvc355_recon_ctu.flags): MARK and RESID commands only, no luma written — the chroma residuals of inter coding units that
+// chroma residual scaling keeps in the walk.  Nothing is staged: the two waves take alternate commands and add their blocks straight on the
+// planes; a block's scale comes from the luma plane (its own CTU's luma is final; a neighbour's once that neighbour's luma flag is up).
+// Inside the CTU every neighbour of a 64x64 unit belongs to an earlier unit of the same CTU (the MARKs of a conforming list say so), at
+// the CTU's edge the neighbour CTU decides (ctb_left / ctb_up), which is what ff_vvc_get_left / top_available answer for one sample.
+template <int BD>
+__device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, const vvc355_recon_ctu &ctu, const ReconCtx &cx, VVC355_GLOBAL int *state,
+                                                const int rs, const int rx, const int ry, const int role, const int tid)
+{
+    using px_t = typename Px<BD>::type;
+    const int ncx = f.ctb_width, n_ctus = ncx * f.ctb_height, ctb = 1 << f.ctb_log2, size_y = min(ctb, 64);
+    if (role == 0) {
+        const int dep[2] = { ((ctu.flags & VVC355_RECON_CTU_LUMA_LEFT) && rx > 0) ? rs - 1 : -1, ((ctu.flags & VVC355_RECON_CTU_LUMA_UP) && ry > 0) ? rs - ncx : -1 };
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            if (dep[d] < 0 || __builtin_amdgcn_readfirstlane(gld<uint32_t>(&((const vvc355_recon_ctu *)f.ctus)[dep[d]].n_cmd)) == 0)
+                continue;                         // (a neighbour without commands never raises a flag: its luma was final before the pass)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&state[kReconFlags + n_ctus + dep[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
+    const uint8_t *luma = (const uint8_t *)f.plane[0];
+    const int ls = f.stride[0] / (int)sizeof(px_t);
+    int xv = -1, yv = -1, scale = 0;
+    for (uint32_t k = (uint32_t)role; k < ctu.n_cmd; k += 2) {
+        const vvc355_recon_cmd c = load_uniform(cmds + k);
+        if (c.kind == VVC355_RECON_MARK)
+            continue;
+        if (c.kind != VVC355_RECON_RESID)
+            __builtin_trap();                    // a LIGHT CTU holds nothing else
+        const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+        if ((c.joint & 8) && (xv != (c.cu_x0 & ~(size_y - 1)) || yv != (c.cu_y0 & ~(size_y - 1)))) {
+            xv = c.cu_x0 & ~(size_y - 1); yv = c.cu_y0 & ~(size_y - 1);
+            const bool avail_l = (xv & (ctb - 1)) ? true : cx.ctb_left != 0;
+            const bool avail_t = (yv & (ctb - 1)) ? true : cx.ctb_up != 0;
+            scale = lmcs_scale_from_plane<BD>((const vvc355_lmcs_model *)f.lmcs_model, luma, ls, xv, yv, size_y, avail_l, avail_t, f.width, f.height, tid);
+        }
+        uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
+        resid_block_add<BD>(dst, f.stride[c_idx], (const int *)c.resid, c.w, c.h, c.joint, scale, tid);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (role == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&state[kReconFlags + n_ctus + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // one CTU: takes the next ticket, returns false when none is left
 template <int BD, bool TILE>
 __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, ReconLds &L, uint16_t *tiles, const int role, const int tid)
@@ -1575,6 +1638,10 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         cx.ctb_up = ry > 0 && !upper_tile && !upper_slice;
         cx.ctb_up_left = cx.ctb_left && cx.ctb_up;
         cx.ox = rx * ctb; cx.oy = ry * ctb;
+    }
+    if (ctu.flags & VVC355_RECON_CTU_LIGHT) {          // workgroup-uniform
+        recon_light_ctu<BD>(f, ctu, cx, state, rs, rx, ry, role, tid);
+        return true;
     }
     // the three planes as the walk sees them: accessor of sample (0, 0) + stride in pixels
     PX pl0, pl1, pl2;
@@ -1888,6 +1955,19 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
 #ifdef VVC355_RECON_PROF
     { unsigned long long *p_ = rprof_lds(); p_[7 + 32 * role] = p_[7 + 32 * role] + (unsigned long long)(clock64() - c_loop); }
 #endif
+    if (role == 0) {
+        // the luma wave is through: what other CTUs read of this CTU's luma (its last kApr rows and columns) goes out now and the luma flag
+        // goes up, ahead of the chroma wave — LIGHT CTUs next to this one wait for nothing else
+        if constexpr (TILE) {
+            const int nk = cw0 >> 2, nr = ch0;
+            recon_tile_store<BD, 5>(tiles + kTileOff[0], kBodyLumaP, (uint8_t *)f.plane[0], f.stride[0], rx * ctb, ry * ctb, max(nr - kApr, 0), nr, 0, nk, tid);
+            recon_tile_store<BD, 0>(tiles + kTileOff[0], kBodyLumaP, (uint8_t *)f.plane[0], f.stride[0], rx * ctb, ry * ctb, 0, max(nr - kApr, 0), nk - 1, nk, tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&state[kReconFlags + ncx * f.ctb_height + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned long long t_join = RPROF_NOW();
     __syncthreads();
     RPROF_ADD(4 + 32 * role, t_join);
@@ -1902,8 +1982,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                 continue;
             uint8_t *plane = (uint8_t *)f.plane[c];
             if (c == 0) {
-                recon_tile_store<BD, 5>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, max(nr - kApr, 0), nr, 0, nk, tid);
-                recon_tile_store<BD, 0>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), nk - 1, nk, tid);
+                // (the luma wave stored its rows and columns before the join)
             } else {
                 recon_tile_store<BD, 4>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, max(nr - kApr, 0), nr, 0, nk, tid);
                 recon_tile_store<BD, 0>(tiles + kTileOff[c], pitch, plane, f.stride[c], (rx * ctb) >> sh, (ry * ctb) >> sh, 0, max(nr - kApr, 0), nk - 1, nk, tid);
@@ -1994,7 +2073,7 @@ void vvc355_recon_prof_read(unsigned long long *out, int reset)
 }
 #endif
 
-size_t vvc355_recon_state_bytes(int n_ctus) { return sizeof(int) * (size_t)(vvc355::kReconFlags + (n_ctus > 0 ? n_ctus : 0)); }
+size_t vvc355_recon_state_bytes(int n_ctus) { return sizeof(int) * (size_t)(vvc355::kReconFlags + 2 * (n_ctus > 0 ? n_ctus : 0)); }
 
 void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *frame_dev, const vvc355_recon_frame *frame_host)
 {

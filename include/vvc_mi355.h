@@ -831,7 +831,18 @@ typedef struct vvc355_recon_cmd {
                                 * for the rest of the CTU as lc->lmcs does (reset per CTU, vvc_intra.c:509-510); needs frame.lmcs_model */
     uint8_t  pad_[6];
 } vvc355_recon_cmd;
-typedef struct vvc355_recon_ctu { uint32_t first_cmd, n_cmd; } vvc355_recon_ctu;
+/*
+ * flags: what the host knows about a CTU's place in the dependency web (0 = an ordinary CTU: it waits for its left, upper-left, upper
+ * and upper-right neighbours that have commands, and is walked on LDS tiles by one wave per channel type).
+ *   LIGHT      the CTU's commands are MARKs and RESIDs only and none touches luma: the chroma residuals of inter coding units that chroma
+ *              residual scaling keeps in the walk (their scale needs the reconstructed luma of a neighbouring CTU the walk writes).  Such a
+ *              CTU is not staged in LDS; its blocks are added straight on the planes, and it waits for nothing but
+ *   LUMA_LEFT / LUMA_UP   the LUMA of its left / upper neighbour CTU (set when that neighbour's luma is written by the walk: the 64x64
+ *              units on that edge read its last column / row, lmcs_derive_chroma_scale vvc_intra_template.c:401-410).  Ordinary CTUs
+ *              publish their luma as soon as their luma commands are done, ahead of their chroma.
+ */
+enum { VVC355_RECON_CTU_LIGHT = 1, VVC355_RECON_CTU_LUMA_LEFT = 2, VVC355_RECON_CTU_LUMA_UP = 4 };
+typedef struct vvc355_recon_ctu { uint32_t first_cmd, n_cmd, flags; } vvc355_recon_ctu;
 typedef struct vvc355_recon_frame {
     uint64_t plane[3];            /* component planes, predicted / reconstructed in place */
     uint64_t cmds, ctus;          /* vvc355_recon_cmd[], vvc355_recon_ctu per CTU (raster order; n_cmd = 0: nothing to do) */

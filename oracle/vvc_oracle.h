@@ -339,7 +339,7 @@ typedef struct orc_recon_cmd {
     uint8_t  kind, c_idx, ref_idx, is_mip, mip_mode, mip_transposed, isp_split, bdpcm_flag, joint;
     uint8_t  pad_[6];
 } orc_recon_cmd;
-typedef struct orc_recon_ctu { uint32_t first_cmd, n_cmd; } orc_recon_ctu;
+typedef struct orc_recon_ctu { uint32_t first_cmd, n_cmd, flags; } orc_recon_ctu;     /* flags: scheduling hints of the device pass, not read here */
 typedef struct orc_recon_frame {
     uint64_t plane[3];
     uint64_t cmds, ctus, order, state;

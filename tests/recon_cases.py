@@ -31,6 +31,7 @@ class ReconWork:
             self.col_bd = np.array([0] * self.ncx + [self.ncx], np.int16)
             self.row_bd = np.array([0] * self.ncy + [self.ncy], np.int16)
         cmds, ctus = [], np.zeros(n_ctb, CTU)
+        kind_of = np.zeros(n_ctb, np.int8)          # 2: the walk writes this CTU's luma (intra / CIIP units); 1: only residuals of inter units (a LIGHT CTU)
         self.resid_len = 0
         self.tbs = []                     # (c_idx, x0, y0 luma, w, h component samples, element offset): what the transform stage must fill
         self.ciip = []                    # (c_idx, x0, y0, w, h luma units, pixel offset into the inter-prediction storage, command index)
@@ -87,6 +88,12 @@ class ReconWork:
             if any_intra or inter_resid:
                 cmds += cu_cmds
                 ctus[rs]["first_cmd"], ctus[rs]["n_cmd"] = first, len(cu_cmds)
+                kind_of[rs] = 2 if any_intra else 1
+        # scheduling hints of the device pass (vvc355_recon_ctu.flags): LIGHT CTUs and whose luma they wait for
+        for rs in np.nonzero(kind_of == 1)[0]:
+            rx, ry = rs % self.ncx, rs // self.ncx
+            ctus[rs]["flags"] = (abi.RECON_CTU_LIGHT | (abi.RECON_CTU_LUMA_LEFT if rx and kind_of[rs - 1] == 2 else 0) |
+                                 (abi.RECON_CTU_LUMA_UP if ry and kind_of[rs - self.ncx] == 2 else 0))
         self.cmds = np.array(cmds, CMD) if cmds else np.zeros(0, CMD)
         self.ctus = ctus
         self.order = np.nonzero(ctus["n_cmd"])[0].astype(np.int32)

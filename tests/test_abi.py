@@ -44,7 +44,7 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.BipredJob) == 104 and ctypes.sizeof(abi.BipredResult) == 32
     assert ctypes.sizeof(abi.AffineJob) == 96
     assert ctypes.sizeof(abi.MvField) == 24 and ctypes.sizeof(abi.BsFrame) == 312
-    assert ctypes.sizeof(abi.ReconCmd) == 40 and ctypes.sizeof(abi.ReconCtu) == 8 and ctypes.sizeof(abi.ReconFrame) == 128 and ctypes.sizeof(abi.LmcsModel) == 72 and ctypes.sizeof(abi.LmcsResidJob) == 56
+    assert ctypes.sizeof(abi.ReconCmd) == 40 and ctypes.sizeof(abi.ReconCtu) == 12 and ctypes.sizeof(abi.ReconFrame) == 128 and ctypes.sizeof(abi.LmcsModel) == 72 and ctypes.sizeof(abi.LmcsResidJob) == 56
     assert ctypes.sizeof(abi.LfnstJob) == 32 and ctypes.sizeof(abi.GpmJob) == 120 and ctypes.sizeof(abi.ItxJob) == 48
     assert ctypes.sizeof(abi.InterPu) == 20 and ctypes.sizeof(abi.InterSlice) == 390 and ctypes.sizeof(abi.InterFrame) == 136 and ctypes.sizeof(abi.RefPic) == 40
     assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136

@@ -117,3 +117,18 @@ def test_recon_lmcs_chroma_residual_scaling(dev, orc, bd, fmt, ctb_log2):
                              resid_ctu=np.ones(n_ctb, bool))
     res = work.cmds[work.cmds["kind"] == abi.RECON_RESID]
     assert ((res["joint"] & 8) != 0).sum() > 100 and ((res["joint"] & 9) == 9).sum() > 3 and ((res["joint"] & 8) == 0).sum() > 50
+
+
+@pytest.mark.parametrize("bd,ctb_log2,w,h", [(10, 7, 1480, 840), (8, 6, 712, 456), (12, 5, 456, 264)])
+def test_recon_lmcs_light_ctus(dev, orc, bd, ctb_log2, w, h):
+    """Whole CTUs of inter coding units among intra CTUs, chroma residual scaling on: the inter CTUs are LIGHT (vvc355_recon_ctu.flags: not
+    staged, residuals added on the planes, waiting only for the luma of an intra neighbour on their left / above, which that neighbour
+    publishes ahead of its chroma), the intra CTUs wait for them like for any neighbour — the result must be the in-order walk's."""
+    rng = np.random.default_rng(0x5EED0EE0 + bd)
+    ctb = 1 << ctb_log2
+    n_ctb = ((w + ctb - 1) // ctb) * ((h + ctb - 1) // ctb)
+    intra_ctu = rng.random(n_ctb) < 0.3
+    work, changed = run_case(dev, orc, rng, bd, w, h, ctb_log2, (1, 1), intra_ctu=intra_ctu, lmcs=True, resid_ctu=~intra_ctu, coded_p=0.8)
+    fl = work.ctus["flags"]
+    assert ((fl & abi.RECON_CTU_LIGHT) != 0).sum() > n_ctb // 3 and ((fl & abi.RECON_CTU_LUMA_LEFT) != 0).sum() > 2 and ((fl & abi.RECON_CTU_LUMA_UP) != 0).sum() > 2
+    assert (fl[work.ctus["n_cmd"] > 0] == 0).sum() > 2
