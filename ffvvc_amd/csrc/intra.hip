@@ -1572,12 +1572,19 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
     const uint8_t *luma = (const uint8_t *)f.plane[0];
     const int ls = f.stride[0] / (int)sizeof(px_t);
     int xv = -1, yv = -1, scale = 0;
-    for (uint32_t k = (uint32_t)role; k < ctu.n_cmd; k += 2) {
-        const vvc355_recon_cmd c = load_uniform(cmds + k);
-        if (c.kind == VVC355_RECON_MARK)
+    // windows of 64 commands: lane i looks at the kind of command win + i (dword 6: mode, kind, c_idx, ref_idx), a ballot gives the
+    // residual blocks of the window, and the two waves take them alternately — only those commands are fetched whole
+    for (uint32_t win = 0; win < ctu.n_cmd; win += 64) {
+      const uint32_t kind = win + tid < ctu.n_cmd ? (gld<uint32_t>((const uint32_t *)(cmds + win + tid) + 6) >> 8) & 0xff : (uint32_t)VVC355_RECON_MARK;
+      if (__builtin_amdgcn_ballot_w64(kind != VVC355_RECON_MARK && kind != VVC355_RECON_RESID))
+          __builtin_trap();                      // a LIGHT CTU holds nothing else
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(kind == VVC355_RECON_RESID);
+      for (int turn = 0; todo; turn ^= 1) {
+        const uint32_t k = win + (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (turn != role)
             continue;
-        if (c.kind != VVC355_RECON_RESID)
-            __builtin_trap();                    // a LIGHT CTU holds nothing else
+        const vvc355_recon_cmd c = load_uniform(cmds + k);
         const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
         if ((c.joint & 8) && (xv != (c.cu_x0 & ~(size_y - 1)) || yv != (c.cu_y0 & ~(size_y - 1)))) {
             xv = c.cu_x0 & ~(size_y - 1); yv = c.cu_y0 & ~(size_y - 1);
@@ -1587,6 +1594,7 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
         }
         uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
         resid_block_add<BD>(dst, f.stride[c_idx], (const int *)c.resid, c.w, c.h, c.joint, scale, tid);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1614,11 +1622,11 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         L.bc[0] = __builtin_amdgcn_readfirstlane(t);
         recon_luma_done_set(L, 0);
     }
+    ((uint32_t *)L.rmap[role])[tid] = 0;             // this wave's channel type starts with nothing reconstructed (both waves are past the previous CTU's last barrier)
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(L.bc[0]);
     if (ticket >= f.n_work)
         return false;
-    ((uint32_t *)L.rmap[role])[tid] = 0;             // this wave's channel type starts with nothing reconstructed (seen by both waves after the next barrier)
     const int rs = __builtin_amdgcn_readfirstlane(gld<int>((const int *)f.order + ticket));
     const vvc355_recon_ctu *ctus = (const vvc355_recon_ctu *)f.ctus;
     const vvc355_recon_ctu ctu = load_uniform(ctus + rs);
@@ -1668,21 +1676,27 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         }
         ps0 = kBodyLumaP; ps1 = kBodyChromaP;
     }
-    // wait for the neighbours this CTU reads: left, upper-left, upper, upper-right (those that have commands)
+    // Wait for the neighbours this wave reads — left, upper-left, upper, upper-right, those that have commands.  The luma wave needs their
+    // LUMA only (flag raised as soon as a neighbour's luma commands are done; a LIGHT neighbour's luma was final before the pass), the
+    // chroma wave the whole neighbour.  From here to the join at the end the two waves run on their own: each waits, loads its own edges
+    // and walks its commands; where the chroma wave reads luma (CCLM, the chroma residual scale) it synchronises on luma_done.
     const unsigned long long t_wait = RPROF_NOW();
-    if (role == 0) {
+    {
+        const int n_ctus = ncx * f.ctb_height;
         const int dep[4] = { rx > 0 ? rs - 1 : -1, (rx > 0 && ry > 0) ? rs - ncx - 1 : -1, ry > 0 ? rs - ncx : -1, (ry > 0 && rx + 1 < ncx) ? rs - ncx + 1 : -1 };
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             if (dep[d] < 0 || __builtin_amdgcn_readfirstlane(gld<uint32_t>(&ctus[dep[d]].n_cmd)) == 0)
                 continue;
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&state[kReconFlags + dep[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+            if (role == 0 && (__builtin_amdgcn_readfirstlane(gld<uint32_t>(&ctus[dep[d]].flags)) & VVC355_RECON_CTU_LIGHT))
+                continue;
+            VVC355_GLOBAL int *flag = &state[kReconFlags + (role == 0 ? n_ctus : 0) + dep[d]];
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
                 __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
     RPROF_ADD(1 + 32 * role, t_wait);
     RPROF_INC(0 + 32 * role);
     const unsigned long long t_load = RPROF_NOW();
@@ -1696,7 +1710,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                                      (rx * ctb) >> sh, (ry * ctb) >> sh, ctb >> sh, ch0 >> sh, f.width >> sh, f.height >> sh, tid);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        group_sync<64>();
     } else {
         pl0 = GPix<BD>{ (uint8_t *)f.plane[0] }; pl1 = GPix<BD>{ (uint8_t *)f.plane[1] }; pl2 = GPix<BD>{ (uint8_t *)f.plane[2] };
         ps0 = f.stride[0] / (int)sizeof(px_t); ps1 = f.stride[1] / (int)sizeof(px_t);
