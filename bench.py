@@ -85,6 +85,7 @@ class Frame:
         self.keep = []
         self.dims = [(width, height), (width // 2, height // 2), (width // 2, height // 2)]
         self.host = {}        # data_ptr -> host copy of every uploaded table (what the `verified` leg mirrors for the oracle)
+        self.derived = {}     # data_ptr -> expected host content of buffers the device writes itself (not part of the per-frame upload)
         self.torch_of = {}
         self.noise = False
         self.ref_frames = None                 # (Frame, Frame): reference pictures = those frames' decoded output (GOP mode); None: synthetic pictures
@@ -133,11 +134,14 @@ class Frame:
         self.keep.append(t)
         return t
 
-    def upload(self, arr):
+    def upload(self, arr, per_frame=True):
+        """A table / descriptor array in HBM.  per_frame: what a decoder sends for every picture (counted and copied by --with-upload);
+        False: buffers the device itself writes every step (stage outputs, tables built from records) — kept with their expected host
+        content for the `verified` leg only."""
         host = np.ascontiguousarray(arr).copy()
         t = self.torch.from_numpy(host).cuda()
         self.keep.append(t)
-        self.host[t.data_ptr()] = host
+        (self.host if per_frame else self.derived)[t.data_ptr()] = host
         self.torch_of[t.data_ptr()] = t
         return t
 
@@ -231,7 +235,7 @@ def build_chain(lib, torch, fr):
     x0, y0 = x0[inter], y0[inter]
     n_blk = len(x0)
     if n_blk:            # (an all-intra picture has no regular inter blocks: --inter-frac 0)
-        d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8))
+        d_rec = fr.upload(np.zeros(n_blk * 32, np.uint8), per_frame=False)          # device scratch: the DMVR records
         mv = rng.integers(-24 * 16, 24 * 16 + 1, size=(n_blk, 4))
         if not fr.noise:
             # half of the blocks carry motion that is consistent with the displacement between the two references, up to one sample
@@ -285,7 +289,24 @@ def build_chain(lib, torch, fr):
             for c in range(3):
                 reft[l * 16].plane[c] = ref_org(l, c)
                 reft[l * 16].stride[c] = ref_pitch(l, c)
-        d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1)), fr.upload(pus.view(np.uint8))
+        # the MvField table itself is written on the device from one 32-byte record per prediction unit (vvc355_tab_fill_pass)
+        d_mvf, d_pus = fr.upload(mvf.view(np.uint8).reshape(-1), per_frame=False), fr.upload(pus.view(np.uint8))
+        mvrec = np.zeros(n_blk, np.dtype([("x0", "<i2"), ("y0", "<i2"), ("w", "u1"), ("h", "u1"), ("pad_", "u1", (2,)), ("mvf", "V24")]))
+        mvrec["x0"], mvrec["y0"], mvrec["w"], mvrec["h"] = x0, y0, bs, bs
+        mvrec["mvf"] = np.ascontiguousarray(mvf[y0 // 4, x0 // 4]).view("V24").reshape(-1)
+        d_mvrec = fr.upload(mvrec.view(np.uint8))
+        mfill = abi.TabFill()
+        mfill.mv, mfill.n_mv, mfill.mvf, mfill.mvf_pitch, mfill.unit_pitch = ptr(d_mvrec), n_blk, ptr(d_mvf), pic_w // 4, pic_w // 4
+        d_mfill = fr.upload(np.frombuffer(bytes(mfill), np.uint8))
+        fr.keep.append(mfill)
+        d_mvf.zero_()
+        lib.vvc355_tab_fill_pass(None, ptr(d_mfill), ctypes.addressof(mfill))
+
+        def check_mvf_fill(fc, orc, env):
+            return n_blk, int(not np.array_equal(env.after[ptr(d_mvf)], fr.derived[ptr(d_mvf)]))
+
+        chain.append(Stage("inter_mvf_fill", "tabfill_kernel", lambda st: lib.vvc355_tab_fill_pass(st, ptr(d_mfill), ctypes.addressof(mfill)),
+                           n_blk * 16 * 24, writes=[d_mvf], check=check_mvf_fill))
         islice = abi.InterSlice()
         islice.lmcs_used = int(LMCS)
         d_reft, d_slices = fr.upload(np.frombuffer(bytes(reft), np.uint8)), fr.upload(np.frombuffer(bytes(islice), np.uint8))
@@ -472,7 +493,7 @@ def build_chain(lib, torch, fr):
 
     # the inter half of the CIIP coding units: plain bi-prediction (CIIP switches DMVR / BDOF off) of every 16x16 (chroma 8x8 or 16x16)
     # tile into packed per-CU blocks that the RECON pass blends with the planar intra prediction
-    d_ciip = fr.upload(np.zeros(max(1, work.ciip_len), np.uint8 if bd == 8 else np.uint16))
+    d_ciip = fr.upload(np.zeros(max(1, work.ciip_len), np.uint8 if bd == 8 else np.uint16), per_frame=False)     # device scratch: inter part of the CIIP units
     cj = []
     for (c, x, y, w, h, off, _k) in work.ciip:
         sh = 1 if c else 0
@@ -529,6 +550,7 @@ def build_chain(lib, torch, fr):
     by_shape = {}              # log2 size -> job arrays of all three planes: one launch per block shape
     windows = []               # (first coefficient, block size, nzw[], nzh[]) of every group of blocks laid out back to back
     ctu_by_shape = {}
+    pos_by_shape = {}          # (x0, y0, component) of every job, in by_shape's order
     coeff_off = 0
     chroma_first = None        # with LMCS: first coefficient (int32 index) of the chroma blocks, whose residuals stay in the buffer for the scaling stage
     cres = []                  # (component, x0, y0, size, first coefficient byte offset) per group of chroma blocks
@@ -575,6 +597,7 @@ def build_chain(lib, torch, fr):
                 j["dst"], j["store_coeffs"] = 0, 1
                 cres.append((c, x0.copy(), y0.copy(), n, j["coeffs"].copy()))
             by_shape.setdefault(lg, []).append(j)
+            pos_by_shape.setdefault(lg, []).append(np.stack([x0, y0, np.full_like(x0, c)], axis=1))
             ctu_by_shape.setdefault(lg, []).append((y0 // cs) * fr.ncx + (x0 // cs))
             windows.append((int(j["coeffs"][0]) // 4, n, j["nzw"].copy(), j["nzh"].copy()))
     if by_shape:         # (no transform blocks outside the intra CTUs in an all-intra picture)
@@ -610,7 +633,43 @@ def build_chain(lib, torch, fr):
         itx_all["dq_flags"] = 1 | (rng.integers(0, 2, size=n_itx) << 1)
         itx_all["dq_qp"] = rng.integers(22, 38, size=n_itx)
         itx_all["log2_matrix_size"], itx_all["dc"] = 1, -1
-        d_itx = fr.upload(itx_all.view(np.uint8))
+        # The 48-byte jobs above are the host's expectation only.  What the device runs is written by vvc355_itx_frame_build from one 16-byte
+        # record per transform block (what the parser leaves in a TransformBlock); the job array is device scratch.
+        pos_all = np.concatenate([np.concatenate(pos_by_shape[lg]) for lg in sorted(by_shape, reverse=True)])
+        tus = np.zeros(n_itx, np.dtype(abi.ItxTu, align=True))
+        tus["coeff_off"] = (itx_all["coeffs"] - coeffs.data_ptr()) // 4
+        tus["x0"], tus["y0"], tus["c_idx"] = pos_all[:, 0], pos_all[:, 1], pos_all[:, 2]
+        for k_ in ("log2_w", "log2_h", "nzw", "nzh"):
+            tus[k_] = itx_all[k_]
+        tus["qp"] = itx_all["dq_qp"]
+        # (with LMCS the chroma blocks' residuals stay in the arena and are scaled by the next stage: bit 6, every 64x64 unit's neighbours exist
+        # except at the picture's left / upper edge — one slice, one tile)
+        cx_l, cy_l = pos_all[:, 0] << (pos_all[:, 2] > 0), pos_all[:, 1] << (pos_all[:, 2] > 0)
+        tus["flags"] = ((itx_all["dq_flags"] & 3) | (itx_all["store_coeffs"] << 2) |
+                        np.where(itx_all["store_coeffs"] != 0, 64 | (((cx_l & ~63) > 0) << 4) | (((cy_l & ~63) > 0) << 5), 0))
+        tus["tr"] = itx_all["trh"] | (itx_all["trv"] << 4)
+        itx_all["c_idx"] = pos_all[:, 2]
+        d_tus = fr.upload(tus.view(np.uint8))
+        d_itx = fr.upload(itx_all.view(np.uint8), per_frame=False)
+        itf = abi.ItxFrame()
+        itf.tus, itf.jobs, itf.coeffs, itf.n_tus = ptr(d_tus), ptr(d_itx), coeffs.data_ptr(), n_itx
+        for c in range(3):
+            itf.plane[c], itf.stride[c] = ptr(rec[c]), fr.pitch(rec[c])
+        itf.range, itf.bd, itf.pixel_shift = 15, bd, int(isz == 2)
+        itf.width, itf.height, itf.hs, itf.vs, itf.size_y = fr.width, fr.height, 1, 1, 64
+        d_rjall = fr.upload(np.zeros(n_itx * ctypes.sizeof(abi.LmcsResidJob), np.uint8), per_frame=False) if (LMCS and chroma_first is not None) else None
+        itf.resid_jobs = ptr(d_rjall) if d_rjall is not None else 0
+        d_itf = fr.upload(np.frombuffer(bytes(itf), np.uint8))
+        fr.keep.append(itf)
+        d_itx.zero_()
+        lib.vvc355_itx_frame_build(None, ptr(d_itf), ctypes.addressof(itf))
+
+        def check_itx_build(fc, orc, env):
+            got = env.after[ptr(d_itx)].view(itx_all.dtype)
+            return n_itx, int(sum(int((got[name] != itx_all[name]).sum()) for name in itx_all.dtype.names if not name.startswith("pad")))
+
+        chain.append(Stage("itx_job_build", "itx_build_kernel", lambda st: lib.vvc355_itx_frame_build(st, ptr(d_itf), ctypes.addressof(itf)),
+                           n_itx * (16 + 48), writes=[d_itx] + ([d_rjall] if d_rjall is not None else []), check=check_itx_build))
 
         scaled = LMCS and chroma_first is not None and chroma_first < n_samples
         if scaled:
@@ -654,8 +713,8 @@ def build_chain(lib, torch, fr):
                 rjs.append(rj)
             rj_all = np.concatenate(rjs)
             ctu_of_rj = np.concatenate([((2 * y0c) // CTB) * fr.ncx + (2 * x0c) // CTB for (_c, x0c, y0c, _n, _o) in cres])
-            d_rj = fr.upload(rj_all.view(np.uint8))
-            n_rj = len(rj_all)
+            # (rj_all is the host's expectation for the check; the device runs the job array the transform-block builder wrote: one slot per
+            # transform block, empty for the blocks that are not scaled here)
 
             def check_lmcs_resid(fc, orc, env):
                 orc.orc_lmcs_chroma_resid_block.argtypes = [ctypes.c_int, ctypes.POINTER(abi.LmcsResidJob), ctypes.POINTER(abi.LmcsModel)]
@@ -678,7 +737,7 @@ def build_chain(lib, torch, fr):
 
             n_cs = int(sum(len(x0c) * n * n for (_c, x0c, _y, n, _o) in cres))
             chain.append(Stage("lmcs_chroma_residual_scale", f"lmcs_chroma_resid_kernel<{bd}>",
-                               lambda st: lib.vvc355_lmcs_chroma_resid_batch(st, bd, ptr(d_rj), n_rj, ptr(d_model)),
+                               lambda st: lib.vvc355_lmcs_chroma_resid_batch(st, bd, ptr(d_rjall), n_itx, ptr(d_model)),
                                n_cs * (4 + 2 * isz), writes=[rec[1], rec[2]], check=check_lmcs_resid))
 
     # ---------------------------------------------------------------- transform blocks of the intra CTUs: scaling process (+ LFNST on a
@@ -771,7 +830,7 @@ def build_chain(lib, torch, fr):
     if len(work.order):
         cmds_dev = work.bind(ptr(res), ptr(d_ciip), isz)
         d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(work.order)
-        d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8))
+        d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8), per_frame=False)
         d_rslice, d_rcol, d_rrow = fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)
         rf = work.frame(rec_ptrs, pitches, ptr(d_cmds), ptr(d_ctus), ptr(d_order), ptr(d_rstate), ptr(d_rslice), ptr(d_rcol), ptr(d_rrow),
                         lmcs_ptr=ptr(d_model) if LMCS else 0)
@@ -880,8 +939,31 @@ def build_chain(lib, torch, fr):
                 if name in ("tbx0", "tbx1", "cbx"):
                     a = a + (np.arange(reps * bt.tw) // bt.tw * (fr.width // reps)).astype(a.dtype)[None, :]
             a = np.ascontiguousarray(a)
-            bs_dev[name] = fr.upload(a.view(np.uint8) if a.dtype.kind == "V" else a)
+            # the per-unit tables are written on the device from records (below), the ten output tables by the bS pass itself: only the
+            # slice / tile maps and the POC lists travel as they are
+            bs_dev[name] = fr.upload(a.view(np.uint8) if a.dtype.kind == "V" else a, per_frame=name not in bt.FILLED + bt.OUT)
+        # what the parser knows per coding unit / transform unit / rectangle of equal motion, repeated across like the tables
+        recs = []
+        for r_ in bt.records():
+            tiled = np.tile(r_, reps)
+            tiled["x0"] += (np.arange(len(tiled)) // len(r_) * (fr.width // reps)).astype(np.int16)
+            recs.append(tiled)
+        d_recs = [fr.upload(r_.view(np.uint8)) for r_ in recs]
         bt.width, bt.tw, bt.cw = fr.width, bt.tw * reps, fr.ncx
+        tfill = bt.fill_frame(ptr(d_recs[0]), ptr(d_recs[1]), ptr(d_recs[2]), tuple(len(r_) for r_ in recs), lambda name: ptr(bs_dev[name]))
+        d_tfill = fr.upload(np.frombuffer(bytes(tfill), np.uint8))
+        fr.keep.append(tfill)
+        filled = [bs_dev[name] for name in bt.FILLED]
+        for t_ in filled:
+            t_.zero_()                                     # the device writes them: nothing of the host's copy is left in HBM
+        lib.vvc355_tab_fill_pass(None, ptr(d_tfill), ctypes.addressof(tfill))
+
+        def check_fill(fc, orc, env):
+            bad = sum(int(not np.array_equal(fr.derived[ptr(t_)].reshape(-1).view(np.uint8), env.after[ptr(t_)].reshape(-1).view(np.uint8))) for t_ in filled)
+            return sum(len(r_) for r_ in recs), bad
+
+        chain.append(Stage("side_tables_fill", "tabfill_kernel", lambda st: lib.vvc355_tab_fill_pass(st, ptr(d_tfill), ctypes.addressof(tfill)),
+                           sum(fr.derived[ptr(t_)].nbytes for t_ in filled), writes=filled, check=check_fill))
         bsf = bt.frame(lambda name: ptr(bs_dev[name]))
         d_bsf = fr.upload(np.frombuffer(bytes(bsf), np.uint8))
         fr.keep.append(bsf)
@@ -893,10 +975,10 @@ def build_chain(lib, torch, fr):
             # whole picture: the oracle fills host copies of the ten output tables, compared entry by entry
             outs = [bs_dev[name] for name in bt.OUT]
             for t in outs:
-                fr.host[ptr(t)][...] = 0xEE
+                fr.derived[ptr(t)][...] = 0xEE
             hf = fc.translate(bsf, env.mirror, fc.BS_IN + fc.BS_OUT)
             orc.orc_deblock_bs_pass(ctypes.byref(hf))
-            bad = sum(int(not np.array_equal(fr.host[ptr(t)].ravel(), env.after[ptr(t)].ravel())) for t in outs)
+            bad = sum(int(not np.array_equal(fr.derived[ptr(t)].ravel(), env.after[ptr(t)].ravel())) for t in outs)
             return n_units, bad
 
         chain.append(Stage("deblock_bs", "deblock_bs_kernel", lambda st: lib.vvc355_deblock_bs_pass(st, ptr(d_bsf), ctypes.addressof(bsf)),
@@ -1035,7 +1117,7 @@ def build_chain(lib, torch, fr):
         af.width, af.height, af.ctb_width, af.ctb_height = fr.width, fr.height, fr.ncx, fr.ncy
         af.ctb_log2, af.hs, af.vs, af.n_comp, af.lfase, af.lfate = 7, 1, 1, 3, 1, 1
         d_af = fr.upload(np.frombuffer(bytes(af), np.uint8))
-        d_awork = fr.upload(np.zeros(lib.vvc355_alf_frame_work_bytes(fr.n_ctus), np.uint8))
+        d_awork = fr.upload(np.zeros(lib.vvc355_alf_frame_work_bytes(fr.n_ctus), np.uint8), per_frame=False)       # device scratch: the ALF job arrays
         fr.keep.append(af)
         chroma_bytes = 2 * fr.dims[1][0] * fr.dims[1][1] * isz
         def check_alf(fc, orc, env):
@@ -1138,7 +1220,7 @@ def verify_step(lib, torch, frame, chain, n_ctus):
     orc = load_oracle()
     fc.bind(orc)
     mirror = fc.Mirror()
-    for dev_ptr, host in frame.host.items():
+    for dev_ptr, host in list(frame.host.items()) + list(frame.derived.items()):
         mirror.add(dev_ptr, host)
     for r in frame.refs:
         for t in r:
@@ -1504,7 +1586,9 @@ def parse_args(argv=None):
                                                         "behind its two reference pictures; 0 = independent frames (--frames-in-flight)")
     ap.add_argument("--frames-in-flight", type=int, default=8, help="independent frames processed concurrently per step (one HIP stream each): the whole step with --gop 0, "
                                                                     "the secondary `independent_frames` figure otherwise; 1 = latency of a single frame")
-    ap.add_argument("--with-upload", action="store_true", help="additionally time the steps with every per-frame descriptor copied from pinned host memory first")
+    ap.add_argument("--with-upload", action="store_true", help="--gop 0: additionally time the steps with every per-frame descriptor copied from pinned host memory first "
+                                                               "(GOP mode always reports it: incl_descriptor_upload)")
+    ap.add_argument("--no-upload", action="store_true", help="GOP mode: skip the incl_descriptor_upload leg")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
     ap.add_argument("--no-lmcs", action="store_true", help="profiling aid: a picture without LMCS (no forward map on the inter prediction, no chroma residual scaling)")
@@ -1632,10 +1716,17 @@ def main(argv=None):
         for f in range(n_ff):
             run_frame(f, events, step, only)
 
-    def run_gop(k, events=None, step=0, only=None):
+    pinned_of = {}
+
+    def run_gop(k, events=None, step=0, only=None, upload=False):
         j = k % n_sets
         for i, (poc, lo, hi) in enumerate(order):
             ts = streams[i % len(streams)]
+            if upload:
+                # what the decoder's host side sends for this picture: every per-frame table, record and descriptor array from pinned memory
+                with torch.cuda.stream(ts):
+                    for dst_t, src_t in pinned_of[(j, poc)]:
+                        dst_t.copy_(src_t, non_blocking=True)
             for dep in {((j - 1) % n_sets, gop) if q == 0 else (j, q) for q in (lo, hi)}:
                 if dep in recorded:
                     ts.wait_event(done_ev[dep])
@@ -1736,7 +1827,27 @@ def main(argv=None):
     # memory at the start of each frame — what a decoder that builds them on the host pays over PCIe (the coefficient levels, which
     # are generated on the device here, are not included: their size is reported).  Measured on the F independent frames.
     upload = None
-    if args.with_upload and not args.graph:
+    if gop and not args.graph and not args.no_upload:
+        for key, fr_i in objs.items():
+            pinned_of[key] = [(fr_i.torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in fr_i.host.items()]
+        up_bytes = sum(h_.nbytes for h_ in frame.host.values())
+        k0 = gop_k[0] + (-gop_k[0]) % n_sets                      # continue the group sequence
+        torch.cuda.synchronize()
+        recorded.clear()
+        for k in range(2):
+            run_gop(k0 + k, upload=True)
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(2, 2 + args.steps):
+            run_gop(k0 + k, upload=True)
+        torch.cuda.synchronize()
+        el_up = sharding.max_over_ranks(dist, torch, world, time.perf_counter() - t1, "cpu")
+        upload = {"value": world * gop * args.steps / el_up, "unit": "frames/s", "descriptor_bytes_per_frame": int(up_bytes),
+                  "ms_per_step": el_up / args.steps * 1e3, "frames_per_step": gop,
+                  "what": "the same groups of pictures with every picture's per-frame tables, records and descriptor arrays copied from pinned host memory "
+                          "on the picture's stream first (the decoder's host side hands them over per picture)",
+                  "not_included": "coefficient levels (int32 in the reference ABI, generated on the device here)"}
+    elif args.with_upload and not args.graph:
         pinned = [[(frames[f].torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in frames[f].host.items()] for f in range(n_ff)]
         up_bytes = sum(h_.nbytes for h_ in frames[0].host.values())
 

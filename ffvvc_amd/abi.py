@@ -135,6 +135,8 @@ BATCH_SIGNATURES = {
     "lfnst_batch":      ("v", "ppi"),
     "recon_frame_pass": ("v", "pipp"),
     "recon_state_bytes": ("z", "i"),
+    "tab_fill_pass":    ("v", "ppp"),
+    "itx_frame_build":  ("v", "ppp"),
 }
 
 
@@ -489,6 +491,44 @@ class LmcsScaleJob(ctypes.Structure):
         ("avail_t", ctypes.c_uint8), ("avail_l", ctypes.c_uint8), ("min_bin_idx", ctypes.c_uint8), ("max_bin_idx", ctypes.c_uint8),
         ("pivot", ctypes.c_uint16 * 17), ("chroma_scale_coeff", ctypes.c_uint16 * 16), ("pad_", ctypes.c_uint16 * 6),
     ]
+
+
+class ItxTu(ctypes.Structure):
+    """Mirror of vvc355_itx_tu."""
+    _fields_ = [("coeff_off", ctypes.c_uint32), ("x0", ctypes.c_int16), ("y0", ctypes.c_int16),
+                ("log2_w", ctypes.c_uint8), ("log2_h", ctypes.c_uint8), ("nzw", ctypes.c_uint8), ("nzh", ctypes.c_uint8),
+                ("c_idx", ctypes.c_uint8), ("qp", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("tr", ctypes.c_uint8)]
+
+
+class ItxFrame(ctypes.Structure):
+    """Mirror of vvc355_itx_frame."""
+    _fields_ = [("tus", ctypes.c_uint64), ("jobs", ctypes.c_uint64), ("coeffs", ctypes.c_uint64), ("plane", ctypes.c_uint64 * 3),
+                ("stride", ctypes.c_int32 * 3), ("n_tus", ctypes.c_int32),
+                ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8), ("pixel_shift", ctypes.c_uint8), ("tu_flags", ctypes.c_uint8),
+                ("resid_jobs", ctypes.c_uint64), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("size_y", ctypes.c_uint8), ("pad_", ctypes.c_uint8)]
+
+
+class CuRec(ctypes.Structure):
+    """Mirror of vvc355_cu_rec / vvc355_tu_rec (same layout)."""
+    _fields_ = [("x0", ctypes.c_int16), ("y0", ctypes.c_int16), ("w", ctypes.c_uint8), ("h", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("pad_", ctypes.c_uint8)]
+
+
+class MvRec(ctypes.Structure):
+    """Mirror of vvc355_mv_rec."""
+    _fields_ = [("x0", ctypes.c_int16), ("y0", ctypes.c_int16), ("w", ctypes.c_uint8), ("h", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2), ("mvf", ctypes.c_int32 * 6)]
+
+
+class TabFill(ctypes.Structure):
+    """Mirror of vvc355_tab_fill / orc_tab_fill."""
+    _fields_ = [("cu", ctypes.c_uint64), ("tu", ctypes.c_uint64), ("mv", ctypes.c_uint64),
+                ("n_cu", ctypes.c_int32), ("n_tu", ctypes.c_int32), ("n_mv", ctypes.c_int32), ("unit_pitch", ctypes.c_int32), ("mvf_pitch", ctypes.c_int32),
+                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+                ("mvf", ctypes.c_uint64),
+                ("tu_coded_flag", ctypes.c_uint64 * 3), ("tu_joint_cbcr", ctypes.c_uint64), ("pcmf", ctypes.c_uint64 * 2),
+                ("tb_pos_x0", ctypes.c_uint64 * 2), ("tb_pos_y0", ctypes.c_uint64 * 2), ("tb_width", ctypes.c_uint64 * 2), ("tb_height", ctypes.c_uint64 * 2),
+                ("cb_pos_x", ctypes.c_uint64), ("cb_pos_y", ctypes.c_uint64), ("cb_width", ctypes.c_uint64), ("cb_height", ctypes.c_uint64),
+                ("msf", ctypes.c_uint64), ("iaf", ctypes.c_uint64)]
 
 
 class LmcsResidJob(ctypes.Structure):

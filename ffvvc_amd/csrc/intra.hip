@@ -1237,6 +1237,8 @@ __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmc
     if (ji >= n_jobs)
         return;
     const vvc355_lmcs_resid_job j = load_uniform(jobs + ji);
+    if (j.w <= 0)
+        return;                 // an empty slot of a job array the transform-block builder wrote (vvc355_itx_frame.resid_jobs)
     const int scale = (j.joint & 8) ? lmcs_scale_from_plane<BD>(model, (const uint8_t *)j.luma, j.luma_stride / (int)sizeof(px_t), j.x_vpdu, j.y_vpdu, j.size_y,
                                                                 j.avail_l != 0, j.avail_t != 0, j.pic_w, j.pic_h, lane) : 0;
     resid_block_add<BD>((uint8_t *)j.dst, j.dst_stride, (const int *)j.resid, j.w, j.h, j.joint, scale, lane);

@@ -836,6 +836,46 @@ static void launch_itx_shape_any(hipStream_t st, const vvc355_itx_job *jobs_dev,
     }
 }
 
+// one lane per transform block record: the 48-byte job the transform kernels consume (vvc355_itx_frame_build)
+__global__ __launch_bounds__(256) void itx_build_kernel(const vvc355_itx_frame *__restrict__ fp)
+{
+    const vvc355_itx_frame f = load_uniform(fp);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f.n_tus)
+        return;
+    const vvc355_itx_tu t = ((const vvc355_itx_tu *)f.tus)[i];
+    vvc355_itx_job j = {};
+    j.coeffs = f.coeffs + (uint64_t)t.coeff_off * 4;
+    const int c = t.c_idx;
+    const uint64_t plane = c == 0 ? f.plane[0] : c == 1 ? f.plane[1] : f.plane[2];
+    const int stride = c == 0 ? f.stride[0] : c == 1 ? f.stride[1] : f.stride[2];
+    const bool keep = (t.flags & 4) != 0;
+    j.dst = keep ? 0 : plane + (uint64_t)t.y0 * stride + ((uint64_t)t.x0 << f.pixel_shift);
+    j.dst_stride = stride;
+    j.trh = t.tr & 15; j.trv = t.tr >> 4;
+    j.log2_w = t.log2_w; j.log2_h = t.log2_h; j.nzw = t.nzw; j.nzh = t.nzh;
+    j.range = f.range; j.bd = f.bd;
+    j.store_coeffs = keep;
+    j.dq_flags = (uint8_t)((t.flags & 1) | (t.flags & 2)); j.dq_qp = t.qp;
+    j.log2_matrix_size = 1; j.dc = -1;
+    j.mts_flags = (t.flags & 8) ? VVC355_ITX_DERIVE_TYPE : 0; j.tu_flags = f.tu_flags; j.c_idx = t.c_idx;
+    ((vvc355_itx_job *)f.jobs)[i] = j;
+    if (f.resid_jobs) {
+        vvc355_lmcs_resid_job r = {};
+        if (t.flags & 64) {
+            r.dst = plane + (uint64_t)t.y0 * stride + ((uint64_t)t.x0 << f.pixel_shift);
+            r.resid = j.coeffs; r.luma = f.plane[0];
+            r.dst_stride = stride; r.luma_stride = f.stride[0];
+            r.w = (int16_t)(1 << t.log2_w); r.h = (int16_t)(1 << t.log2_h);
+            r.x_vpdu = (int16_t)((t.x0 << (c ? f.hs : 0)) & ~(f.size_y - 1)); r.y_vpdu = (int16_t)((t.y0 << (c ? f.vs : 0)) & ~(f.size_y - 1));
+            r.pic_w = (int16_t)f.width; r.pic_h = (int16_t)f.height; r.size_y = f.size_y;
+            r.avail_l = (t.flags >> 4) & 1; r.avail_t = (t.flags >> 5) & 1;
+            r.joint = 8;
+        }
+        ((vvc355_lmcs_resid_job *)f.resid_jobs)[i] = r;
+    }
+}
+
 } // namespace vvc355
 
 using namespace vvc355;
@@ -854,6 +894,13 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
         else if (max_log2_area <= 10) hipLaunchKernelGGL((itx_kernel<BD, 256, 1024>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
         else                          hipLaunchKernelGGL((itx_kernel<BD, 256, 4096>), dim3(n_jobs), dim3(256), 0, st, jobs_dev, n_jobs);
     });
+    HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_itx_frame_build(void *stream, const vvc355_itx_frame *frame_dev, const vvc355_itx_frame *frame_host)
+{
+    if (frame_host->n_tus <= 0) return;
+    hipLaunchKernelGGL(vvc355::itx_build_kernel, dim3((frame_host->n_tus + 255) / 256), dim3(256), 0, (hipStream_t)stream, frame_dev);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -291,6 +291,40 @@ void vvc355_itx_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int 
 void vvc355_itx_shape_batch(void *stream, int bd, const vvc355_itx_job *jobs_dev, int n_jobs, int log2_w, int log2_h);
 
 /*
+ * The transform-block job list of a picture written on the device from one 16-byte record per transform block — what the parser leaves
+ * in a TransformBlock (vvc_ctu.h:136-160) — instead of 48-byte jobs built and uploaded by the host: the TU loop of itransform
+ * (vvc_intra.c:431-472) as a descriptor builder.  The jobs land in `jobs` (DEVICE scratch, n_tus entries, same order as the records) and
+ * go to vvc355_itx_shape_batch / vvc355_itx_batch like host-built ones.
+ *   coeff_off   first coefficient of the block in the picture's coefficient arena (tb->coeffs - fc->tab.coeffs), int32 elements
+ *   x0, y0      position in the component's samples; nzw, nzh = max_scan_x + 1, max_scan_y + 1
+ *   flags       bit 0: fused scaling process (flat matrix, m = 16); bit 1: sh_dep_quant_used_flag; bit 2: the residual stays in the arena
+ *               (store_coeffs, no add: blocks whose residual another stage adds); bit 3: derive the transform types on the device
+ *               (VVC355_ITX_DERIVE_TYPE with tu_flags / mts_idx / lfnst_idx = the frame's defaults); tr = trh | trv << 4 otherwise;
+ *               bit 6 (with bit 2, chroma blocks): the residual is scaled and added by vvc355_lmcs_chroma_resid_batch — the job is written to
+ *               frame.resid_jobs, its 64x64 unit from the block's position, bits 4 / 5 = that unit's left / upper luma neighbours exist
+ *               (ff_vvc_get_left / top_available(lc, x_vpdu, y_vpdu, 1, 0))
+ */
+typedef struct vvc355_itx_tu {
+    uint32_t coeff_off;
+    int16_t  x0, y0;
+    uint8_t  log2_w, log2_h, nzw, nzh;
+    uint8_t  c_idx, qp, flags, tr;
+} vvc355_itx_tu;
+typedef struct vvc355_itx_frame {
+    uint64_t tus, jobs, coeffs;   /* DEVICE: records, job scratch, coefficient arena */
+    uint64_t plane[3];
+    int32_t  stride[3];           /* bytes */
+    int32_t  n_tus;
+    uint8_t  range, bd, pixel_shift, tu_flags;
+    /* chroma residual scaling outside the in-order pass: with resid_jobs != 0 the builder also writes one vvc355_lmcs_resid_job per record
+     * (DEVICE scratch, n_tus entries, same order; w = 0 — a job the batch entry skips — for blocks without flags bit 6) */
+    uint64_t resid_jobs;
+    int32_t  width, height;       /* luma picture size */
+    uint8_t  hs, vs, size_y, pad_;      /* chroma shifts; min(CtbSizeY, 64) */
+} vvc355_itx_frame;
+void vvc355_itx_frame_build(void *stream, const vvc355_itx_frame *frame_dev, const vvc355_itx_frame *frame_host);
+
+/*
  * Scaling process for transform coefficients (dequant) — NOT a table slot in the reference: host C in
  * vvc_intra.c:277-417 (derive_qp :277, derive_scale :311, derive_scale_m :341, scale_coeff :391, dequant :400),
  * called per transform block right before LFNST / itx (vvc_intra.c:455-462).  Flattened: everything read through
@@ -662,8 +696,42 @@ typedef struct vvc355_mvfield {             /* MvField, vvc_ctu.h:195-202 (same 
     uint8_t pad_[2];
 } vvc355_mvfield;
 
+/* ------------------------------------------------------------------ side tables from compact records (tabfill.hip) */
+
+/*
+ * The per-unit tables above, written on the device from what the parser knows per unit, instead of being filled on the host and uploaded
+ * (24 bytes of MvField + ~60 bytes of positions, sizes and flags per 4x4 luma unit).  One record per call site of the reference's table
+ * setters; coordinates in luma samples, sizes multiples of 4 up to 128:
+ *   vvc355_cu_rec   a coding unit of the luma (or single) tree: set_cb_pos + set_cb_tab of msf / iaf (vvc_ctu.c:1144-1160, :1230-1238)
+ *                   flags bit 0 = MergeSubblockFlag, bit 1 = InterAffineFlag
+ *   vvc355_tu_rec   a transform unit of one tree: set_tb_pos + set_tb_tab (:41-75, :395-400, :511, :1247).  flags bit 7 = tree (0: luma / single
+ *                   tree -> tb_*[0], tu_coded_flag[0], pcmf[0]; 1: chroma tree -> tb_*[1] in chroma samples, tu_coded_flag[1..2], joint, pcmf[1]),
+ *                   bits 0..2 = tu_coded_flag of Y / Cb / Cr, bit 3 = tu_joint_cbcr_residual_flag, bit 4 = pcm flag
+ *   vvc355_mv_rec   a rectangle of equal motion (a prediction unit, or one sub-block of a sub-block unit): ff_vvc_set_mvf (vvc_mvs.c)
+ * Records of one kind may be given in any order as long as rectangles of that kind do not overlap (a parser's never do within a tree).
+ * unit_pitch = 4x4 units per table row (min_tu_width = min_pu_width = min_cb_width for MinCbLog2SizeY = 2), mvf_pitch likewise for mvf.
+ */
+typedef struct vvc355_cu_rec { int16_t x0, y0; uint8_t w, h, flags, pad_; } vvc355_cu_rec;
+typedef struct vvc355_tu_rec { int16_t x0, y0; uint8_t w, h, flags, pad_; } vvc355_tu_rec;
+typedef struct vvc355_mv_rec {
+    int16_t x0, y0; uint8_t w, h, pad_[2];
+    int32_t mvf[6];               /* a vvc355_mvfield (24 bytes; declared below) */
+} vvc355_mv_rec;
+typedef struct vvc355_tab_fill {
+    uint64_t cu, tu, mv;          /* DEVICE record arrays */
+    int32_t  n_cu, n_tu, n_mv;
+    int32_t  unit_pitch, mvf_pitch;
+    uint8_t  hs, vs, pad_[2];
+    /* DEVICE tables to write (any of them may be shared with vvc355_bs_frame / vvc355_inter_frame / vvc355_deblock_frame) */
+    uint64_t mvf;
+    uint64_t tu_coded_flag[3], tu_joint_cbcr, pcmf[2];
+    uint64_t tb_pos_x0[2], tb_pos_y0[2], tb_width[2], tb_height[2];
+    uint64_t cb_pos_x, cb_pos_y, cb_width, cb_height, msf, iaf;
+} vvc355_tab_fill;
+void vvc355_tab_fill_pass(void *stream, const vvc355_tab_fill *frame_dev, const vvc355_tab_fill *frame_host);
+
 typedef struct vvc355_bs_frame {
-    /* inputs: the decoder's side tables (VVCFrameContext.tab, vvcdec.h:122-187), uploaded as they are */
+    /* inputs: the decoder's side tables (VVCFrameContext.tab, vvcdec.h:122-187), uploaded as they are or written by vvc355_tab_fill_pass */
     uint64_t mvf;                 /* vvc355_mvfield per 4x4 luma unit, row pitch min_pu_width */
     uint64_t ref_poc;             /* int32 [slice][2][32]: RefPicList.list[] (POCs) of the slice's two lists */
     uint64_t slice_idx;           /* int16 per CTB */

@@ -365,3 +365,44 @@ ORC_API void orc_lmcs_chroma_resid_block(int bd, const orc_lmcs_resid_job *j, co
     }
     orc_add_residual(bd, dst, tmp, j->w, j->h, j->dst_stride);
 }
+
+/* The side tables from per-unit records, one table entry per 4x4 luma unit of every record's rectangle — the loops of set_cb_pos /
+ * set_cb_tab (vvc_ctu.c:124-140, :1144-1160), set_tb_pos / set_tb_tab (:41-75) and ff_vvc_set_mvf (vvc_mvs.c) with the values the call
+ * sites pass (:395-400, :511, :1230-1250). */
+ORC_API void orc_tab_fill_pass(const orc_tab_fill *f)
+{
+#define TAB(type, addr) ((type *)(uintptr_t)(addr))
+    const orc_cu_rec *cu = TAB(const orc_cu_rec, f->cu);
+    for (int i = 0; i < f->n_cu; i++)
+        for (int y = cu[i].y0 >> 2; y < (cu[i].y0 + cu[i].h) >> 2; y++)
+            for (int x = cu[i].x0 >> 2; x < (cu[i].x0 + cu[i].w) >> 2; x++) {
+                const int u = y * f->unit_pitch + x;
+                TAB(int, f->cb_pos_x)[u] = cu[i].x0; TAB(int, f->cb_pos_y)[u] = cu[i].y0;
+                TAB(uint8_t, f->cb_width)[u] = cu[i].w; TAB(uint8_t, f->cb_height)[u] = cu[i].h;
+                TAB(uint8_t, f->msf)[u] = cu[i].flags & 1; TAB(uint8_t, f->iaf)[u] = (cu[i].flags >> 1) & 1;
+            }
+    const orc_tu_rec *tu = TAB(const orc_tu_rec, f->tu);
+    for (int i = 0; i < f->n_tu; i++) {
+        const int tree = tu[i].flags >> 7;
+        for (int y = tu[i].y0 >> 2; y < (tu[i].y0 + tu[i].h) >> 2; y++)
+            for (int x = tu[i].x0 >> 2; x < (tu[i].x0 + tu[i].w) >> 2; x++) {
+                const int u = y * f->unit_pitch + x;
+                TAB(int, f->tb_pos_x0[tree])[u] = tu[i].x0; TAB(int, f->tb_pos_y0[tree])[u] = tu[i].y0;
+                TAB(uint8_t, f->tb_width[tree])[u] = (uint8_t)(tree ? tu[i].w >> f->hs : tu[i].w);
+                TAB(uint8_t, f->tb_height[tree])[u] = (uint8_t)(tree ? tu[i].h >> f->vs : tu[i].h);
+                TAB(uint8_t, f->pcmf[tree])[u] = (tu[i].flags >> 4) & 1;
+                if (!tree) {
+                    TAB(uint8_t, f->tu_coded_flag[0])[u] = tu[i].flags & 1;
+                } else {
+                    TAB(uint8_t, f->tu_coded_flag[1])[u] = (tu[i].flags >> 1) & 1; TAB(uint8_t, f->tu_coded_flag[2])[u] = (tu[i].flags >> 2) & 1;
+                    TAB(uint8_t, f->tu_joint_cbcr)[u] = (tu[i].flags >> 3) & 1;
+                }
+            }
+    }
+    const orc_mv_rec *mv = TAB(const orc_mv_rec, f->mv);
+    for (int i = 0; i < f->n_mv; i++)
+        for (int y = mv[i].y0 >> 2; y < (mv[i].y0 + mv[i].h) >> 2; y++)
+            for (int x = mv[i].x0 >> 2; x < (mv[i].x0 + mv[i].w) >> 2; x++)
+                memcpy(TAB(uint8_t, f->mvf) + (size_t)(y * f->mvf_pitch + x) * 24, mv[i].mvf, 24);
+#undef TAB
+}

@@ -356,6 +356,21 @@ typedef struct orc_lmcs_model {
     uint8_t  pad_[4];
 } orc_lmcs_model;
 void orc_recon_frame_pass(int bd, const orc_recon_frame *f);
+/* same layouts as vvc355_cu_rec / _tu_rec / _mv_rec / _tab_fill: the side tables from per-unit records (what set_cb_pos / set_cb_tab, set_tb_pos /
+ * set_tb_tab and ff_vvc_set_mvf write per minimum unit, vvc_ctu.c:41-140, :1144-1250) */
+typedef struct orc_cu_rec { int16_t x0, y0; uint8_t w, h, flags, pad_; } orc_cu_rec;
+typedef struct orc_tu_rec { int16_t x0, y0; uint8_t w, h, flags, pad_; } orc_tu_rec;
+typedef struct orc_mv_rec { int16_t x0, y0; uint8_t w, h, pad_[2]; int32_t mvf[6]; } orc_mv_rec;
+typedef struct orc_tab_fill {
+    uint64_t cu, tu, mv;
+    int32_t  n_cu, n_tu, n_mv, unit_pitch, mvf_pitch;
+    uint8_t  hs, vs, pad_[2];
+    uint64_t mvf;
+    uint64_t tu_coded_flag[3], tu_joint_cbcr, pcmf[2];
+    uint64_t tb_pos_x0[2], tb_pos_y0[2], tb_width[2], tb_height[2];
+    uint64_t cb_pos_x, cb_pos_y, cb_width, cb_height, msf, iaf;
+} orc_tab_fill;
+void orc_tab_fill_pass(const orc_tab_fill *f);
 /* same layout as vvc355_lmcs_resid_job: one chroma block's residual scaled (lmcs_scale_chroma) and added outside the in-order walk */
 typedef struct orc_lmcs_resid_job {
     uint64_t dst, resid, luma;

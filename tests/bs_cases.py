@@ -79,6 +79,8 @@ class BsTables:
         self.ref_poc = rng.choice(np.array([0, 4, 8], np.int32), size=(max(1, n_slices), 2, 32)).astype(np.int32)
         gmv = rng.integers(-40, 41, size=(2, 2))
         self.split, self.cbf_p = split, cbf_p
+        # the same information as per-unit records (what the parser knows when it calls the table setters): vvc355_tab_fill_pass input
+        self.cu_recs, self.tu_recs, self.mv_recs = [], [], []
         for ry in range(self.ch):
             for rx in range(self.cw):
                 self._ctb(rng, rx * ctb, ry * ctb, ctb, gmv, inter_frac)
@@ -117,6 +119,13 @@ class BsTables:
                     for by in range(0, h, 8):
                         for bx in range(0, w, 8):
                             self.mvf[(y + by) // 4:(y + by + 8) // 4, (x + bx) // 4:(x + bx + 8) // 4]["mv"] = base + rng.integers(-7, 8, size=(2, 2))
+            self.cu_recs.append((x, y, w, h, int(self.msf[y // 4, x // 4]) | (int(self.iaf[y // 4, x // 4]) << 1), 0))
+            if inter and (self.msf[y // 4, x // 4] or self.iaf[y // 4, x // 4]):
+                for by in range(0, h, 8):
+                    for bx in range(0, w, 8):
+                        self.mv_recs.append((x + bx, y + by, 8, 8, self.mvf[(y + by) // 4, (x + bx) // 4].tobytes()))
+            else:
+                self.mv_recs.append((x, y, w, h, self.mvf[y // 4, x // 4].tobytes()))           # intra units: the zero MvField (ff_vvc_set_intra_mvf)
             # luma transform units: the coding block, or 2 / 4 strips of it
             parts = [(x, y, w, h)]
             r = rng.random()
@@ -130,10 +139,12 @@ class BsTables:
                 ts = self._fill_tu(0, tx, ty, tw, th, 0)
                 self.cbf0[ts] = int(rng.random() < self.cbf_p)
                 self.pcm0[ts] = int(rng.random() < 0.2)
+                self.tu_recs.append((tx, ty, tw, th, int(self.cbf0[ty // 4, tx // 4]) | (int(self.pcm0[ty // 4, tx // 4]) << 4), 0))
             if not dual:
                 ts = self._fill_tu(1, x, y, w, h, 1)
                 self.cbf1[ts], self.cbf2[ts] = int(rng.random() < 0.3), int(rng.random() < 0.3)
                 self.joint[ts], self.pcm1[ts] = int(rng.random() < 0.1), int(rng.random() < 0.2)
+                self._tu1_rec(x, y, w, h)
         if dual:
             cl = []
             _split(rng, x0, y0, ctb, ctb, self.width, self.height, 16, cl, *self.split)
@@ -141,6 +152,41 @@ class BsTables:
                 ts = self._fill_tu(1, x, y, w, h, 1)
                 self.cbf1[ts], self.cbf2[ts] = int(rng.random() < 0.3), int(rng.random() < 0.3)
                 self.joint[ts], self.pcm1[ts] = int(rng.random() < 0.1), int(rng.random() < 0.2)
+                self._tu1_rec(x, y, w, h)
+
+    def _tu1_rec(self, x, y, w, h):
+        u = (y // 4, x // 4)
+        self.tu_recs.append((x, y, w, h, 0x80 | (int(self.cbf1[u]) << 1) | (int(self.cbf2[u]) << 2) | (int(self.joint[u]) << 3) | (int(self.pcm1[u]) << 4), 0))
+
+    def records(self):
+        """(cu, tu, mv) record arrays with the layouts of vvc355_cu_rec / _tu_rec / _mv_rec."""
+        rec_dt = np.dtype(abi.CuRec, align=True)
+        mv_dt = np.dtype([("x0", "<i2"), ("y0", "<i2"), ("w", "u1"), ("h", "u1"), ("pad_", "u1", (2,)), ("mvf", "V24")])
+        cu, tu = np.array(self.cu_recs, rec_dt), np.array(self.tu_recs, rec_dt)
+        mv = np.zeros(len(self.mv_recs), mv_dt)
+        for i, (x, y, w, h, raw) in enumerate(self.mv_recs):
+            mv[i] = (x, y, w, h, (0, 0), raw)
+        return cu, tu, mv
+
+    def fill_frame(self, cu_ptr, tu_ptr, mv_ptr, n, ptr_of):
+        """vvc355_tab_fill for this picture's tables (ptr_of(name) = address of the table `name`)."""
+        f = abi.TabFill()
+        f.cu, f.tu, f.mv = cu_ptr, tu_ptr, mv_ptr
+        f.n_cu, f.n_tu, f.n_mv = n
+        f.unit_pitch = f.mvf_pitch = self.tw
+        f.hs, f.vs = self.hs, self.vs
+        f.mvf = ptr_of("mvf")
+        for c in range(3):
+            f.tu_coded_flag[c] = ptr_of(f"cbf{c}")
+        f.tu_joint_cbcr = ptr_of("joint")
+        for t in range(2):
+            f.pcmf[t], f.tb_pos_x0[t], f.tb_pos_y0[t] = ptr_of(f"pcm{t}"), ptr_of(f"tbx{t}"), ptr_of(f"tby{t}")
+            f.tb_width[t], f.tb_height[t] = ptr_of(f"tbw{t}"), ptr_of(f"tbh{t}")
+        f.cb_pos_x, f.cb_pos_y, f.cb_width, f.cb_height = ptr_of("cbx"), ptr_of("cby"), ptr_of("cbw"), ptr_of("cbh")
+        f.msf, f.iaf = ptr_of("msf"), ptr_of("iaf")
+        return f
+
+    FILLED = ("mvf", "cbf0", "cbf1", "cbf2", "joint", "pcm0", "pcm1", "tbx0", "tbx1", "tby0", "tby1", "tbw0", "tbw1", "tbh0", "tbh1", "cbx", "cby", "cbw", "cbh", "msf", "iaf")
 
     def frame(self, ptr_of):
         f = abi.BsFrame()
