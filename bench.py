@@ -294,9 +294,12 @@ def build_chain(lib, torch, fr):
         mvrec = np.zeros(n_blk, np.dtype([("x0", "<i2"), ("y0", "<i2"), ("w", "u1"), ("h", "u1"), ("pad_", "u1", (2,)), ("mvf", "V24")]))
         mvrec["x0"], mvrec["y0"], mvrec["w"], mvrec["h"] = x0, y0, bs, bs
         mvrec["mvf"] = np.ascontiguousarray(mvf[y0 // 4, x0 // 4]).view("V24").reshape(-1)
-        d_mvrec = fr.upload(mvrec.view(np.uint8))
+        import bs_cases as _bsc
+        mvrec, mv_first = _bsc.BsTables.group_per_ctu(mvrec, 7, fr.ncx, fr.n_ctus)
+        d_mvrec, d_mvfirst = fr.upload(mvrec.view(np.uint8)), fr.upload(mv_first)
         mfill = abi.TabFill()
         mfill.mv, mfill.n_mv, mfill.mvf, mfill.mvf_pitch, mfill.unit_pitch = ptr(d_mvrec), n_blk, ptr(d_mvf), pic_w // 4, pic_w // 4
+        mfill.ctu_first_mv, mfill.ctb_log2, mfill.width, mfill.height, mfill.ctb_width, mfill.ctb_height = ptr(d_mvfirst), 7, fr.width, fr.height, fr.ncx, fr.ncy
         d_mfill = fr.upload(np.frombuffer(bytes(mfill), np.uint8))
         fr.keep.append(mfill)
         d_mvf.zero_()
@@ -948,9 +951,13 @@ def build_chain(lib, torch, fr):
             tiled = np.tile(r_, reps)
             tiled["x0"] += (np.arange(len(tiled)) // len(r_) * (fr.width // reps)).astype(np.int16)
             recs.append(tiled)
+        grouped = [bt.group_per_ctu(r_, 7, fr.ncx, fr.n_ctus) for r_ in recs]           # per CTU, raster order: how a parser produces them
+        recs = [g_[0] for g_ in grouped]
         d_recs = [fr.upload(r_.view(np.uint8)) for r_ in recs]
+        d_firsts = [fr.upload(g_[1]) for g_ in grouped]
         bt.width, bt.tw, bt.cw = fr.width, bt.tw * reps, fr.ncx
-        tfill = bt.fill_frame(ptr(d_recs[0]), ptr(d_recs[1]), ptr(d_recs[2]), tuple(len(r_) for r_ in recs), lambda name: ptr(bs_dev[name]))
+        tfill = bt.fill_frame(ptr(d_recs[0]), ptr(d_recs[1]), ptr(d_recs[2]), tuple(len(r_) for r_ in recs), lambda name: ptr(bs_dev[name]),
+                              tuple(ptr(d_) for d_ in d_firsts))
         d_tfill = fr.upload(np.frombuffer(bytes(tfill), np.uint8))
         fr.keep.append(tfill)
         filled = [bs_dev[name] for name in bt.FILLED]
@@ -1423,6 +1430,25 @@ def host_cpu():
     return model, os.cpu_count() or 1, usable
 
 
+def cgroup_cpu_quota():
+    """CPU time this process's cgroup may use, in cores (cgroup v2 cpu.max, else v1 cfs quota), or None when unlimited / unreadable:
+    sched_getaffinity can list every hardware thread of the host while the container is granted a fraction of them."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(root, fr, budget_s, max_workers=0):
     """The CPU oracle (kind "port") timed on the host: first on ONE core, then on every core this process may run on (one worker
     process per core, each repeating whole CTUs — one CTU per task, no shared state), over a bounded sample of the same per-CTU work:
@@ -1432,7 +1458,9 @@ def cpu_baseline(root, fr, budget_s, max_workers=0):
     one = cpu_chain(root, fr.bd)
     n1, dt1 = cpu_time_chain(one, min(6.0, budget_s / 2))
     one_core = (n1 / fr.n_ctus) / dt1
-    cores = usable if max_workers <= 0 else min(usable, max_workers)
+    quota = cgroup_cpu_quota()
+    granted = usable if quota is None else max(1, min(usable, int(quota + 0.5)))          # workers beyond the CPU quota only time-share
+    cores = granted if max_workers <= 0 else min(granted, max_workers)
     t_each = max(2.0, budget_s - dt1 - 2.0)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", f"{t_each:.2f}", "--bd", str(fr.bd)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
@@ -1446,13 +1474,16 @@ def cpu_baseline(root, fr, budget_s, max_workers=0):
         rate += d["ctus"] / d["s"]
         n_all += d["ctus"]
         t_max = max(t_max, d["s"])
+    # what the workers really got: the aggregate rate in units of the one-core rate (contention, SMT siblings and quotas show up here)
+    effective = (rate / fr.n_ctus) / one_core if one_core > 0 else float(cores)
     return {
         "value": rate / fr.n_ctus,
         "unit": "frames/s",
         "cores": cores,
+        "effective_cores": round(effective, 1),
         "kind": "port",
         "one_core": one_core,
-        "host": {"cpu_model": model, "nproc": nproc, "usable": usable},
+        "host": {"cpu_model": model, "nproc": nproc, "usable_by_affinity": usable, "cgroup_cpu_quota_cores": quota},
         "sample": f"{n_all} CTUs in {t_max:.1f} s on {cores} worker processes ({n1} CTUs in {dt1:.1f} s on one core first); a frame is "
                   f"{fr.n_ctus} CTUs (128x128, {fr.bd}-bit 4:2:0); each CTU goes through the same stage chain as one inter CTU (bi-prediction "
                   f"with DMVR + BDOF, dequant + itx + residual, LMCS, boundary strengths, deblock, SAO, ALF + CC-ALF)",

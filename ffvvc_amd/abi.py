@@ -523,7 +523,9 @@ class TabFill(ctypes.Structure):
     """Mirror of vvc355_tab_fill / orc_tab_fill."""
     _fields_ = [("cu", ctypes.c_uint64), ("tu", ctypes.c_uint64), ("mv", ctypes.c_uint64),
                 ("n_cu", ctypes.c_int32), ("n_tu", ctypes.c_int32), ("n_mv", ctypes.c_int32), ("unit_pitch", ctypes.c_int32), ("mvf_pitch", ctypes.c_int32),
-                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 2),
+                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("ctb_log2", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
+                ("ctu_first_cu", ctypes.c_uint64), ("ctu_first_tu", ctypes.c_uint64), ("ctu_first_mv", ctypes.c_uint64),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32), ("ctb_height", ctypes.c_int32),
                 ("mvf", ctypes.c_uint64),
                 ("tu_coded_flag", ctypes.c_uint64 * 3), ("tu_joint_cbcr", ctypes.c_uint64), ("pcmf", ctypes.c_uint64 * 2),
                 ("tb_pos_x0", ctypes.c_uint64 * 2), ("tb_pos_y0", ctypes.c_uint64 * 2), ("tb_width", ctypes.c_uint64 * 2), ("tb_height", ctypes.c_uint64 * 2),

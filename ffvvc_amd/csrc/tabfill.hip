@@ -5,79 +5,106 @@
 // ff_vvc_set_mvf and friends per prediction unit or sub-block (vvc_mvs.c).  A frame-resident backend needs those tables in HBM for the
 // boundary-strength pass, the deblocking parameter derivation and the inter stage driver; uploading them as they are costs 24 + ~60 bytes
 // per 4x4 luma unit (180 MB of an 8K picture).  Here the host hands over what the parser knows per unit — 8 bytes per coding unit,
-// 8 per transform unit, 32 per rectangle of equal motion — and one launch writes the tables: a wave per record, lanes over the record's
-// 4x4 units, coalesced row segments.
+// 8 per transform unit, 32 per rectangle of equal motion, grouped per CTU like the parser produces them — and one launch writes the tables.
+//
+// One workgroup per CTU.  Phase 1 inverts the records: each record (16 lanes per record) writes its index into an LDS map of the CTU's
+// 4x4 units, one map per table family (coding unit, transform unit of each tree, motion).  Phase 2 walks the CTU's units in raster order,
+// one lane per unit: the unit's record comes through the map (an 8- or 32-byte load that neighbouring lanes share) and every table gets
+// its entry — rows of 32 consecutive units, so the byte tables go out as 32-byte segments, the int tables as 128-byte lines and the
+// MvField table as 768-byte runs.
 #include "common.hpp"
 #include "runtime.hpp"
 #include "../../include/vvc_mi355.h"
 
 namespace vvc355 {
 
-// records per workgroup: 4 waves, one record each
-template <typename REC, typename F>
-__device__ __forceinline__ void for_units(const REC &r, int pitch, int lane, F body)
+static constexpr int kMaxUnits = 32 * 32;          // 128x128 CTU in 4x4 units
+static constexpr uint16_t kNoRec = 0xffff;
+
+// records [first, last) of one kind -> map[unit within the CTU] = record index - first
+template <typename REC>
+__device__ __forceinline__ void map_records(uint16_t *map, const REC *recs, int first, int last, int ox, int oy, int lw, int tree_filter)
 {
-    const int ux = r.x0 >> 2, uy = r.y0 >> 2, uw = r.w >> 2, uh = r.h >> 2;          // 4x4 luma units; w, h are multiples of 4
-    const int n = uw * uh;
-    for (int i = lane; i < n; i += 64) {
-        const int dy = i / uw, dx = i - dy * uw;
-        body((uy + dy) * pitch + ux + dx);
+    const int sub = threadIdx.x & 15;
+    for (int r = first + (threadIdx.x >> 4); r < last; r += 16) {
+        const uint2 head = gld<uint2>(recs + r);               // x0 y0 | w h flags pad: the same 8 bytes for all three record kinds
+        const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff, flags = (head.y >> 16) & 0xff;
+        if (tree_filter >= 0 && (flags >> 7) != tree_filter)
+            continue;
+        const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
+        for (int i = sub; i < n; i += 16) {
+            const int dy = i / uw, dx = i - dy * uw;
+            map[((uy + dy) << lw) + ux + dx] = (uint16_t)(r - first);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void tabfill_kernel(const vvc355_tab_fill *__restrict__ fp)
 {
+    __shared__ uint16_t map[4][kMaxUnits];             // coding unit, transform unit tree 0, tree 1, motion
     const vvc355_tab_fill f = load_uniform(fp);
-    const int rec = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int pitch = f.unit_pitch;
-    if (rec < f.n_cu) {
-        const vvc355_cu_rec r = load_uniform((const vvc355_cu_rec *)f.cu + rec);
-        int *cbx = (int *)f.cb_pos_x, *cby = (int *)f.cb_pos_y;
-        uint8_t *cbw = (uint8_t *)f.cb_width, *cbh = (uint8_t *)f.cb_height, *msf = (uint8_t *)f.msf, *iaf = (uint8_t *)f.iaf;
-        for_units(r, pitch, lane, [&](int u) {
-            gst<int>(cbx + u, r.x0); gst<int>(cby + u, r.y0);
-            gst<uint8_t>(cbw + u, r.w); gst<uint8_t>(cbh + u, r.h);
-            gst<uint8_t>(msf + u, (uint8_t)(r.flags & 1)); gst<uint8_t>(iaf + u, (uint8_t)((r.flags >> 1) & 1));
-        });
-        return;
-    }
-    const int t = rec - f.n_cu;
-    if (t < f.n_tu) {
-        const vvc355_tu_rec r = load_uniform((const vvc355_tu_rec *)f.tu + t);
-        const int tree = r.flags >> 7;
-        int *tbx = (int *)f.tb_pos_x0[tree], *tby = (int *)f.tb_pos_y0[tree];
-        uint8_t *tbw = (uint8_t *)f.tb_width[tree], *tbh = (uint8_t *)f.tb_height[tree], *pcm = (uint8_t *)f.pcmf[tree];
-        const uint8_t wv = (uint8_t)(tree ? r.w >> f.hs : r.w), hv = (uint8_t)(tree ? r.h >> f.vs : r.h);      // in samples of the tree's component
-        if (!tree) {
-            uint8_t *cbf0 = (uint8_t *)f.tu_coded_flag[0];
-            for_units(r, pitch, lane, [&](int u) {
-                gst<int>(tbx + u, r.x0); gst<int>(tby + u, r.y0); gst<uint8_t>(tbw + u, wv); gst<uint8_t>(tbh + u, hv);
-                gst<uint8_t>(cbf0 + u, (uint8_t)(r.flags & 1)); gst<uint8_t>(pcm + u, (uint8_t)((r.flags >> 4) & 1));
-            });
-        } else {
-            uint8_t *cbf1 = (uint8_t *)f.tu_coded_flag[1], *cbf2 = (uint8_t *)f.tu_coded_flag[2], *jnt = (uint8_t *)f.tu_joint_cbcr;
-            for_units(r, pitch, lane, [&](int u) {
-                gst<int>(tbx + u, r.x0); gst<int>(tby + u, r.y0); gst<uint8_t>(tbw + u, wv); gst<uint8_t>(tbh + u, hv);
-                gst<uint8_t>(cbf1 + u, (uint8_t)((r.flags >> 1) & 1)); gst<uint8_t>(cbf2 + u, (uint8_t)((r.flags >> 2) & 1));
-                gst<uint8_t>(jnt + u, (uint8_t)((r.flags >> 3) & 1)); gst<uint8_t>(pcm + u, (uint8_t)((r.flags >> 4) & 1));
-            });
+    const int rs = blockIdx.x, ry = rs / f.ctb_width, rx = rs - ry * f.ctb_width;
+    const int lw = f.ctb_log2 - 2, side = 1 << lw, n_units = side * side;
+    const int ox = rx << f.ctb_log2, oy = ry << f.ctb_log2;
+    for (int i = threadIdx.x; i < 4 * kMaxUnits / 2; i += 256)
+        ((uint32_t *)map)[i] = 0xffffffffu;
+    __syncthreads();
+    const int *fcu = (const int *)f.ctu_first_cu, *ftu = (const int *)f.ctu_first_tu, *fmv = (const int *)f.ctu_first_mv;
+    const int cu0 = fcu ? gld<int>(fcu + rs) : 0, cu1 = fcu ? gld<int>(fcu + rs + 1) : 0;
+    const int tu0 = ftu ? gld<int>(ftu + rs) : 0, tu1 = ftu ? gld<int>(ftu + rs + 1) : 0;
+    const int mv0 = fmv ? gld<int>(fmv + rs) : 0, mv1 = fmv ? gld<int>(fmv + rs + 1) : 0;
+    const vvc355_cu_rec *cus = (const vvc355_cu_rec *)f.cu;
+    const vvc355_tu_rec *tus = (const vvc355_tu_rec *)f.tu;
+    const vvc355_mv_rec *mvs = (const vvc355_mv_rec *)f.mv;
+    map_records(map[0], cus, cu0, cu1, ox, oy, lw, -1);
+    map_records(map[1], tus, tu0, tu1, ox, oy, lw, 0);
+    map_records(map[2], tus, tu0, tu1, ox, oy, lw, 1);
+    // (motion records are 32 bytes: the head is their first 8)
+    {
+        const int sub = threadIdx.x & 15;
+        for (int r = mv0 + (threadIdx.x >> 4); r < mv1; r += 16) {
+            const uint2 head = gld<uint2>(mvs + r);
+            const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff;
+            const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
+            for (int i = sub; i < n; i += 16) {
+                const int dy = i / uw, dx = i - dy * uw;
+                map[3][((uy + dy) << lw) + ux + dx] = (uint16_t)(r - mv0);
+            }
         }
-        return;
     }
-    const int m = t - f.n_tu;
-    if (m < f.n_mv) {
-        const vvc355_mv_rec r = load_uniform((const vvc355_mv_rec *)f.mv + m);
-        uint4 lo;
-        uint2 hi;
-        __builtin_memcpy(&lo, &r.mvf, 16);
-        __builtin_memcpy(&hi, (const uint8_t *)&r.mvf + 16, 8);
-        uint8_t *tab = (uint8_t *)f.mvf;
-        const int mp = f.mvf_pitch;
-        const int ux = r.x0 >> 2, uy = r.y0 >> 2, uw = r.w >> 2, n = uw * (r.h >> 2);
-        for (int i = lane; i < n; i += 64) {
-            const int dy = i / uw, dx = i - dy * uw;
-            uint8_t *e = tab + (size_t)((uy + dy) * mp + ux + dx) * 24;
-            gst<uint2>(e, make_uint2(lo.x, lo.y)); gst<uint2>(e + 8, make_uint2(lo.z, lo.w)); gst<uint2>(e + 16, hi);        // 24-byte entries: 8-byte aligned
+    __syncthreads();
+    const int pw = f.width >> 2, ph = f.height >> 2;                // picture size in units
+    for (int i = threadIdx.x; i < n_units; i += 256) {
+        const int dy = i >> lw, dx = i & (side - 1);
+        const int gx = (ox >> 2) + dx, gy = (oy >> 2) + dy;
+        if (gx >= pw || gy >= ph)
+            continue;
+        const int u = gy * f.unit_pitch + gx;
+        const uint16_t ic = map[0][i], i0 = map[1][i], i1 = map[2][i], im = map[3][i];
+        if (ic != kNoRec) {
+            const vvc355_cu_rec r = gld<vvc355_cu_rec>(cus + cu0 + ic);
+            gst<int>((int *)f.cb_pos_x + u, r.x0); gst<int>((int *)f.cb_pos_y + u, r.y0);
+            gst<uint8_t>((uint8_t *)f.cb_width + u, r.w); gst<uint8_t>((uint8_t *)f.cb_height + u, r.h);
+            gst<uint8_t>((uint8_t *)f.msf + u, (uint8_t)(r.flags & 1)); gst<uint8_t>((uint8_t *)f.iaf + u, (uint8_t)((r.flags >> 1) & 1));
+        }
+        if (i0 != kNoRec) {
+            const vvc355_tu_rec r = gld<vvc355_tu_rec>(tus + tu0 + i0);
+            gst<int>((int *)f.tb_pos_x0[0] + u, r.x0); gst<int>((int *)f.tb_pos_y0[0] + u, r.y0);
+            gst<uint8_t>((uint8_t *)f.tb_width[0] + u, r.w); gst<uint8_t>((uint8_t *)f.tb_height[0] + u, r.h);
+            gst<uint8_t>((uint8_t *)f.tu_coded_flag[0] + u, (uint8_t)(r.flags & 1)); gst<uint8_t>((uint8_t *)f.pcmf[0] + u, (uint8_t)((r.flags >> 4) & 1));
+        }
+        if (i1 != kNoRec) {
+            const vvc355_tu_rec r = gld<vvc355_tu_rec>(tus + tu0 + i1);
+            gst<int>((int *)f.tb_pos_x0[1] + u, r.x0); gst<int>((int *)f.tb_pos_y0[1] + u, r.y0);
+            gst<uint8_t>((uint8_t *)f.tb_width[1] + u, (uint8_t)(r.w >> f.hs)); gst<uint8_t>((uint8_t *)f.tb_height[1] + u, (uint8_t)(r.h >> f.vs));      // in chroma samples
+            gst<uint8_t>((uint8_t *)f.tu_coded_flag[1] + u, (uint8_t)((r.flags >> 1) & 1)); gst<uint8_t>((uint8_t *)f.tu_coded_flag[2] + u, (uint8_t)((r.flags >> 2) & 1));
+            gst<uint8_t>((uint8_t *)f.tu_joint_cbcr + u, (uint8_t)((r.flags >> 3) & 1)); gst<uint8_t>((uint8_t *)f.pcmf[1] + u, (uint8_t)((r.flags >> 4) & 1));
+        }
+        if (im != kNoRec) {
+            const uint8_t *src = (const uint8_t *)(mvs + mv0 + im) + 8;
+            const uint2 a = gld<uint2>(src), b = gld<uint2>(src + 8), c = gld<uint2>(src + 16);
+            uint8_t *e = (uint8_t *)f.mvf + (size_t)(gy * f.mvf_pitch + gx) * 24;
+            gst<uint2>(e, a); gst<uint2>(e + 8, b); gst<uint2>(e + 16, c);
         }
     }
 }
@@ -86,8 +113,12 @@ __global__ __launch_bounds__(256) void tabfill_kernel(const vvc355_tab_fill *__r
 
 extern "C" void vvc355_tab_fill_pass(void *stream, const vvc355_tab_fill *frame_dev, const vvc355_tab_fill *frame_host)
 {
-    const int n = frame_host->n_cu + frame_host->n_tu + frame_host->n_mv;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(vvc355::tabfill_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, frame_dev);
+    const int n = frame_host->ctb_width * frame_host->ctb_height;
+    if (n <= 0 || frame_host->n_cu + frame_host->n_tu + frame_host->n_mv <= 0) return;
+    if (frame_host->ctb_log2 < 5 || frame_host->ctb_log2 > 7) {
+        fprintf(stderr, "vvc_mi355: vvc355_tab_fill_pass: CTB log2 size %d outside 5..7\n", frame_host->ctb_log2);
+        abort();
+    }
+    hipLaunchKernelGGL(vvc355::tabfill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, frame_dev);
     HIP_CHECK(hipGetLastError());
 }

@@ -1,7 +1,7 @@
 """Multi-GPU plumbing: the hot path shards by independent stream / frame, so ranks exchange no pixel data.
 
 Only two things cross ranks: a barrier around the timed region and the max of the per-rank elapsed times.  Both go
-through torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+through torch.distributed with the "gloo" backend, on the GPU box and in the CPU tests alike: two host scalars, no RCCL traffic."""
 from __future__ import annotations
 
 

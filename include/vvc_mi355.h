@@ -708,7 +708,9 @@ typedef struct vvc355_mvfield {             /* MvField, vvc_ctu.h:195-202 (same 
  *                   tree -> tb_*[0], tu_coded_flag[0], pcmf[0]; 1: chroma tree -> tb_*[1] in chroma samples, tu_coded_flag[1..2], joint, pcmf[1]),
  *                   bits 0..2 = tu_coded_flag of Y / Cb / Cr, bit 3 = tu_joint_cbcr_residual_flag, bit 4 = pcm flag
  *   vvc355_mv_rec   a rectangle of equal motion (a prediction unit, or one sub-block of a sub-block unit): ff_vvc_set_mvf (vvc_mvs.c)
- * Records of one kind may be given in any order as long as rectangles of that kind do not overlap (a parser's never do within a tree).
+ * Records are grouped per CTU, CTUs in raster order, the way a parser produces them: ctu_first_*[rs] .. ctu_first_*[rs + 1] is CTU rs's
+ * range in the record array of that kind (int32, ctb_width * ctb_height + 1 entries; 0 = no records of that kind at all).  Within a CTU
+ * any order, rectangles of one kind (and tree) do not overlap and lie inside the CTU.  A CTU holds at most 65535 records of a kind.
  * unit_pitch = 4x4 units per table row (min_tu_width = min_pu_width = min_cb_width for MinCbLog2SizeY = 2), mvf_pitch likewise for mvf.
  */
 typedef struct vvc355_cu_rec { int16_t x0, y0; uint8_t w, h, flags, pad_; } vvc355_cu_rec;
@@ -721,7 +723,9 @@ typedef struct vvc355_tab_fill {
     uint64_t cu, tu, mv;          /* DEVICE record arrays */
     int32_t  n_cu, n_tu, n_mv;
     int32_t  unit_pitch, mvf_pitch;
-    uint8_t  hs, vs, pad_[2];
+    uint8_t  hs, vs, ctb_log2, pad_;
+    uint64_t ctu_first_cu, ctu_first_tu, ctu_first_mv;     /* DEVICE int32[ctb_width * ctb_height + 1] each, or 0 */
+    int32_t  width, height, ctb_width, ctb_height;         /* luma picture size; CTUs per row / column */
     /* DEVICE tables to write (any of them may be shared with vvc355_bs_frame / vvc355_inter_frame / vvc355_deblock_frame) */
     uint64_t mvf;
     uint64_t tu_coded_flag[3], tu_joint_cbcr, pcmf[2];

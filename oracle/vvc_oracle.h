@@ -364,7 +364,9 @@ typedef struct orc_mv_rec { int16_t x0, y0; uint8_t w, h, pad_[2]; int32_t mvf[6
 typedef struct orc_tab_fill {
     uint64_t cu, tu, mv;
     int32_t  n_cu, n_tu, n_mv, unit_pitch, mvf_pitch;
-    uint8_t  hs, vs, pad_[2];
+    uint8_t  hs, vs, ctb_log2, pad_;
+    uint64_t ctu_first_cu, ctu_first_tu, ctu_first_mv;     /* the device pass's grouping of the records per CTU; not read here */
+    int32_t  width, height, ctb_width, ctb_height;
     uint64_t mvf;
     uint64_t tu_coded_flag[3], tu_joint_cbcr, pcmf[2];
     uint64_t tb_pos_x0[2], tb_pos_y0[2], tb_width[2], tb_height[2];

@@ -168,11 +168,20 @@ class BsTables:
             mv[i] = (x, y, w, h, (0, 0), raw)
         return cu, tu, mv
 
-    def fill_frame(self, cu_ptr, tu_ptr, mv_ptr, n, ptr_of):
+    @staticmethod
+    def group_per_ctu(recs, ctb_log2, ctb_width, n_ctb):
+        """Records ordered by CTU (raster) and the int32 ranges ctu_first[n_ctb + 1] vvc355_tab_fill wants."""
+        rs = (recs["y0"].astype(np.int64) >> ctb_log2) * ctb_width + (recs["x0"].astype(np.int64) >> ctb_log2)
+        order = np.argsort(rs, kind="stable")
+        return np.ascontiguousarray(recs[order]), np.searchsorted(rs[order], np.arange(n_ctb + 1)).astype(np.int32)
+
+    def fill_frame(self, cu_ptr, tu_ptr, mv_ptr, n, ptr_of, first_ptrs=(0, 0, 0)):
         """vvc355_tab_fill for this picture's tables (ptr_of(name) = address of the table `name`)."""
         f = abi.TabFill()
         f.cu, f.tu, f.mv = cu_ptr, tu_ptr, mv_ptr
         f.n_cu, f.n_tu, f.n_mv = n
+        f.ctu_first_cu, f.ctu_first_tu, f.ctu_first_mv = first_ptrs
+        f.ctb_log2, f.width, f.height, f.ctb_width, f.ctb_height = self.ctb_log2, self.width, self.height, self.cw, self.ch
         f.unit_pitch = f.mvf_pitch = self.tw
         f.hs, f.vs = self.hs, self.vs
         f.mvf = ptr_of("mvf")

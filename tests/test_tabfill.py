@@ -37,15 +37,18 @@ def test_records_reproduce_the_parsers_tables(orc, fmt, ctb_log2):
 @pytest.mark.parametrize("fmt,ctb_log2,w,h", [((1, 1), 7, 1480, 840), ((1, 0), 6, 328, 200), ((0, 0), 5, 136, 104)])
 def test_tab_fill_pass(dev, orc, fmt, ctb_log2, w, h):
     t = bs_cases.BsTables(np.random.default_rng(0x5EED0F10 + ctb_log2), w, h, ctb_log2, hs=fmt[0], vs=fmt[1])
-    cu, tu, mv = t.records()
+    n_ctb = t.cw * t.ch
+    grouped = [t.group_per_ctu(r, ctb_log2, t.cw, n_ctb) for r in t.records()]
+    (cu, tu, mv), firsts = [g[0] for g in grouped], [g[1] for g in grouped]
     want = _oracle_tables(orc, t, cu, tu, mv)
     d_rec = [batch.DeviceBuffer.from_host(a.view(np.uint8)) for a in (cu, tu, mv)]
+    d_first = [batch.DeviceBuffer.from_host(a) for a in firsts]
     d_tab = {}
     for name in t.FILLED:
         init = np.zeros_like(getattr(t, name))
         init.view(np.uint8)[:] = 0x5A
         d_tab[name] = batch.DeviceBuffer.from_host(init.view(np.uint8))
-    f = t.fill_frame(d_rec[0].ptr, d_rec[1].ptr, d_rec[2].ptr, (len(cu), len(tu), len(mv)), lambda n: d_tab[n].ptr)
+    f = t.fill_frame(d_rec[0].ptr, d_rec[1].ptr, d_rec[2].ptr, (len(cu), len(tu), len(mv)), lambda n: d_tab[n].ptr, tuple(d.ptr for d in d_first))
     d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(f), np.uint8))
     dev.vvc355_tab_fill_pass(None, d_f.ptr, ctypes.addressof(f))
     dev.vvc355_stream_sync(None)
