@@ -86,6 +86,7 @@ class Frame:
         self.dims = [(width, height), (width // 2, height // 2), (width // 2, height // 2)]
         self.host = {}        # data_ptr -> host copy of every uploaded table (what the `verified` leg mirrors for the oracle)
         self.derived = {}     # data_ptr -> expected host content of buffers the device writes itself (not part of the per-frame upload)
+        self.arena, self.arena_host, self.arena_used, self.pin = None, None, 0, False
         self.torch_of = {}
         self.noise = False
         self.ref_frames = None                 # (Frame, Frame): reference pictures = those frames' decoded output (GOP mode); None: synthetic pictures
@@ -138,7 +139,26 @@ class Frame:
         """A table / descriptor array in HBM.  per_frame: what a decoder sends for every picture (counted and copied by --with-upload);
         False: buffers the device itself writes every step (stage outputs, tables built from records) — kept with their expected host
         content for the `verified` leg only."""
-        host = np.ascontiguousarray(arr).copy()
+        src = np.ascontiguousarray(arr)
+        if per_frame:
+            # everything a picture's host side sends lives in one device arena with a pinned host twin: one copy per picture
+            if self.arena is None:
+                cap = max(1 << 20, int(self.width * self.height * 2.6))
+                self.arena = self.torch.zeros(cap, dtype=self.torch.uint8, device="cuda")
+                self.arena_host = self.torch.zeros(cap, dtype=self.torch.uint8).pin_memory() if self.pin else self.torch.zeros(cap, dtype=self.torch.uint8)
+                self.keep.append(self.arena)
+            at = (self.arena_used + 255) & ~255
+            if at + src.nbytes <= self.arena.numel():
+                self.arena_used = at + src.nbytes
+                hv = self.arena_host.numpy()[at:at + src.nbytes]
+                hv[:] = src.reshape(-1).view(np.uint8)
+                host = hv.view(src.dtype).reshape(src.shape)
+                t = self.arena[at:at + src.nbytes].view(getattr(self.torch, str(src.dtype))).view(src.shape) if src.dtype.kind != "V" else self.arena[at:at + src.nbytes]
+                t.copy_(self.torch.from_numpy(host) if src.dtype.kind != "V" else self.torch.from_numpy(hv))
+                self.host[t.data_ptr()] = host
+                self.torch_of[t.data_ptr()] = t
+                return t
+        host = src.copy()
         t = self.torch.from_numpy(host).cuda()
         self.keep.append(t)
         (self.host if per_frame else self.derived)[t.data_ptr()] = host
@@ -1691,6 +1711,8 @@ def main(argv=None):
     if gop:
         order = gop_order(gop)
         objs = {(j, poc): Frame(torch, args.width, args.height, args.bd, seed=0x5EED0001 + rank + 977 * (j * gop + poc)) for j in range(n_sets) for poc in range(1, gop + 1)}
+        for fr_i in objs.values():
+            fr_i.pin = not args.no_upload            # the per-frame arena's host twin is pinned: the upload leg copies from it
 
         def ref_obj(j, poc):
             return objs[((j - 1) % n_sets, gop)] if poc == 0 else objs[(j, poc)]
@@ -1860,7 +1882,9 @@ def main(argv=None):
     upload = None
     if gop and not args.graph and not args.no_upload:
         for key, fr_i in objs.items():
-            pinned_of[key] = [(fr_i.torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in fr_i.host.items()]
+            lo_, hi_ = fr_i.arena.data_ptr(), fr_i.arena.data_ptr() + fr_i.arena.numel()
+            pinned_of[key] = [(fr_i.arena[:fr_i.arena_used], fr_i.arena_host[:fr_i.arena_used])]          # one copy: the picture's arena
+            pinned_of[key] += [(fr_i.torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in fr_i.host.items() if not lo_ <= p_ < hi_]
         up_bytes = sum(h_.nbytes for h_ in frame.host.values())
         k0 = gop_k[0] + (-gop_k[0]) % n_sets                      # continue the group sequence
         torch.cuda.synchronize()
