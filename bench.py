@@ -57,6 +57,9 @@ TC_TABLE = [0] * 18 + [3, 4, 4, 4, 4, 5, 5, 5, 5, 7, 7, 8, 9, 10, 10, 11, 13, 14
 BETA_TABLE = [0] * 16 + list(range(6, 19)) + list(range(20, 90, 2))
 
 
+_GENERATED = {}                # host-side generator results shared by the frame objects of a run (same seeds, same partitions)
+
+
 class Stage:
     """One batched launch (or a few launches of the same kernel) of the hot path over the whole frame."""
 
@@ -511,8 +514,13 @@ def build_chain(lib, torch, fr):
     # the residual adds through the in-order wavefront pass further down
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import recon_cases
-    work = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1), ciip_ctu=ctu_ciip,
-                                 lmcs=LMCS, resid_ctu=ctu_dep if LMCS else None)
+    # (every frame object of a run describes the same partition — the generators are seeded with constants — so the host-side generation
+    # is done once per process and shared; the per-frame arrays with addresses in them are bound per object below)
+    wkey = ("work", fr.width, fr.height, LMCS, ctu_inter.tobytes(), ctu_ciip.tobytes())
+    if wkey not in _GENERATED:
+        _GENERATED[wkey] = recon_cases.ReconWork(np.random.default_rng(0x5EED0EC0), fr.width, fr.height, 7, 1, 1, intra_ctu=~ctu_inter, split=(0.6, 0.1), ciip_ctu=ctu_ciip,
+                                                 lmcs=LMCS, resid_ctu=ctu_dep if LMCS else None)
+    work = _GENERATED[wkey]
 
     # the inter half of the CIIP coding units: plain bi-prediction (CIIP switches DMVR / BDOF off) of every 16x16 (chroma 8x8 or 16x16)
     # tile into packed per-CU blocks that the RECON pass blends with the planar intra prediction
@@ -949,7 +957,12 @@ def build_chain(lib, torch, fr):
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
         import bs_cases
         reps = next(r for r in (4, 3, 2, 1) if fr.width % (r * CTB) == 0 or r == 1)
-        bt = bs_cases.BsTables(np.random.default_rng(0x5EED0B5), fr.width // reps, fr.height, 7, split=(0.95, 0.45), cbf_p=0.4)
+        bkey = ("bs", fr.width // reps, fr.height)
+        if bkey not in _GENERATED:
+            bt0 = bs_cases.BsTables(np.random.default_rng(0x5EED0B5), fr.width // reps, fr.height, 7, split=(0.95, 0.45), cbf_p=0.4)
+            _GENERATED[bkey] = (bt0, bt0.records())
+        import copy
+        bt, bt_records = copy.copy(_GENERATED[bkey][0]), _GENERATED[bkey][1]
         bs_dev = {}
         for name in bt.IN + bt.OUT:
             a = getattr(bt, name)
@@ -967,7 +980,7 @@ def build_chain(lib, torch, fr):
             bs_dev[name] = fr.upload(a.view(np.uint8) if a.dtype.kind == "V" else a, per_frame=name not in bt.FILLED + bt.OUT)
         # what the parser knows per coding unit / transform unit / rectangle of equal motion, repeated across like the tables
         recs = []
-        for r_ in bt.records():
+        for r_ in bt_records:
             tiled = np.tile(r_, reps)
             tiled["x0"] += (np.arange(len(tiled)) // len(r_) * (fr.width // reps)).astype(np.int16)
             recs.append(tiled)

@@ -749,6 +749,19 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const vvc355_intra_job 
 
 // ------------------------------------------------------------------------------------------------ host side
 
+// A context that claims neighbours where the picture has none would make the kernels read in front of the staged window (a GPU memory
+// fault, which the runtime turns into a bare abort of the process): such calls are outside the slots' domain and end here, with a message.
+// (Round 2's unexplained abort in tests/test_host_shim.py was exactly this: lmcs_scale_chroma for a CTU in the picture's first row with
+// lc->ctb_up_flag = 1, i.e. avail_t at y = 0.)
+static void check_neighbours(const char *slot, int x, int y, int left, int top, int up_left)
+{
+    if (x < 0 || y < 0 || (left && x == 0) || (top && y == 0) || (up_left && (x == 0 || y == 0))) {
+        fprintf(stderr, "vvc_mi355: %s at (%d, %d) claims neighbours outside the picture (left %d, top %d, up-left %d): outside the slot's domain\n",
+                slot, x, y, left, top, up_left);
+        abort();
+    }
+}
+
 static void check_intra_dims(int w, int h)
 {
     if (w <= 0 || h <= 0 || w > 128 || h > 128 || (w & (w - 1)) || (h & (h - 1))) {
@@ -870,6 +883,7 @@ void vvc355_pred_mip(int bd, uint8_t *src, const uint8_t *top, const uint8_t *le
 void vvc355_intra_pred_flat(int bd, const vvc355_intra_job *job)
 {
     check_intra_dims(job->w, job->h);
+    check_neighbours("intra_pred", job->x, job->y, job->left_avail, job->top_avail, job->cand_up_left);
     const int px = bd > 8 ? 2 : 1;
     // window of the plane the slot can touch: 4 reference lines up/left, up to cb + block (ISP) or 2x block samples down/right
     const int reach_x = job->w + (job->isp_split && !job->c_idx ? (job->cb_width > job->w ? job->cb_width : job->w) : job->w) + 4;
@@ -1266,6 +1280,7 @@ void vvc355_cclm_batch(void *stream, int bd, const vvc355_cclm_job *jobs_dev, in
 void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h)
 {
     using namespace vvc355;
+    check_neighbours("intra_cclm_pred", job->x0, job->y0, job->left_avail_c || job->avail_l, job->top_avail_c || job->avail_t, 0);
     const int px = bd > 8 ? 2 : 1;
     const int hs = job->hs, vs = job->vs;
     // luma window: block + 2 rows above, 3 columns left, 1 extra row/column, and the T/L extension (2x the block)
@@ -1303,6 +1318,7 @@ void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int
 {
     using namespace vvc355;
     if (width <= 0 || height <= 0) return;
+    check_neighbours("lmcs_scale_chroma", job->x_vpdu, job->y_vpdu, job->avail_l, job->avail_t, 0);
     const int px = bd > 8 ? 2 : 1, n = width * height;
     const int x = job->x_vpdu, y = job->y_vpdu;
     const int x0 = x > 0 ? x - 1 : 0, y0 = y > 0 ? y - 1 : 0;

@@ -522,10 +522,10 @@ __device__ __forceinline__ void bipred_tools(const vvc355_bipred_job *job, Tools
     // columns doubled (ring replication) and nothing from beyond the block; the sum lands in lane 4 bx + 2
     {
         const int e = (x == 0 || x == W - 1) ? 1 : 0;
-        // Scheduling fence on both sides: with v_dot2c (the vertical sums above) interleaved between these DPP instructions the
-        // right-looking pair of lane 15 came back as zero on gfx950 (ROCm 7.2; no wait-state rule covers it) — bit-exactness
-        // failed on the right-most sub-block only.  Kept apart, the sequence is exact.
-        __builtin_amdgcn_sched_barrier(0);
+        // (Round 2 kept this block between two __builtin_amdgcn_sched_barrier(0) after a build in which lane 15's right-looking pair read
+        // zero.  Round 3 could not reproduce it: the ISA with and without the fences differs only in where the hazard recogniser puts the
+        // VALU-write -> DPP-read wait states (s_nop), present in both, and the unfenced library passes every bi-prediction parity test
+        // including test_bdof_rightmost_subblock — so the failure belonged to that intermediate source state, not to the instruction mix.)
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             int p = tot[q] << e;
@@ -536,7 +536,6 @@ __device__ __forceinline__ void bipred_tools(const vvc355_bipred_job *job, Tools
             const int tl = p + dpp0<kDppShr1>(p), tr = p + dpp0<kDppShl1>(p);
             tot[q] = tl + dpp0<kDppShr2>(tl) + dpp0<kDppShl1>(tr);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     const int sgx2 = tot[0], sgy2 = tot[1], sgxgy = tot[2], sgxdi = tot[3], sgydi = tot[4];
     const int vx = sgx2 > 0 ? clip3((sgxdi * 4) >> ilog2(sgx2), -15, 15) : 0;

@@ -48,3 +48,25 @@ def test_job_struct_sizes_match_header():
     assert ctypes.sizeof(abi.LfnstJob) == 32 and ctypes.sizeof(abi.GpmJob) == 120 and ctypes.sizeof(abi.ItxJob) == 48
     assert ctypes.sizeof(abi.InterPu) == 20 and ctypes.sizeof(abi.InterSlice) == 390 and ctypes.sizeof(abi.InterFrame) == 136 and ctypes.sizeof(abi.RefPic) == 40
     assert ctypes.sizeof(abi.AlfCtb) == 8 and ctypes.sizeof(abi.AlfSlice) == 160 and ctypes.sizeof(abi.AlfFrame) == 136
+
+
+def test_flat_slots_reject_neighbours_outside_the_picture():
+    """A context that claims an upper neighbour for a block in the picture's first row (round 2's unexplained abort: lmcs_scale_chroma with
+    lc->ctb_up_flag = 1 at y = 0 read in front of the staged window — a GPU memory fault, a bare abort) is outside the slots' domain:
+    the library says so and aborts before touching the device.  Runs without a GPU (the check precedes every HIP call)."""
+    import subprocess
+    import sys
+    code = f"""
+import ctypes, sys
+sys.path.insert(0, {ROOT!r})
+from ffvvc_amd import abi
+lib = ctypes.CDLL(abi.LIB_PATH)
+j = abi.LmcsScaleJob()
+j.x_vpdu, j.y_vpdu, j.pic_w, j.pic_h, j.size_y, j.avail_t, j.avail_l = 192, 0, 256, 128, 64, 1, 1
+buf = (ctypes.c_int * 16)()
+lib.vvc355_lmcs_scale_chroma_flat.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+lib.vvc355_lmcs_scale_chroma_flat(10, ctypes.byref(j), buf, buf, 4, 4)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
+    assert r.returncode == -6, (r.returncode, r.stderr[-300:])
+    assert b"lmcs_scale_chroma at (192, 0) claims neighbours outside the picture" in r.stderr

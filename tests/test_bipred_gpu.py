@@ -214,3 +214,43 @@ def test_gpm_batch(dev, orc, bd, fmt):
         bad = np.argwhere(got != want[c])
         assert len(bad) == 0, f"component {c}: {len(bad)} samples differ, first at {bad[0].tolist()}"
     assert np.any(want[0] != 0x33)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_bdof_rightmost_subblock(dev, orc, bd):
+    """BDOF's 6x6 window sums of the right-most 4x4 sub-block of a 16-wide block are the ones whose right-looking pair is anchored on the
+    row's last lane (mc_tools.hpp, horizontal box sums by DPP row shifts): pictures that are flat except for texture in a block's last six
+    columns make exactly those sums — and nothing else — decide the output."""
+    bc.bind_oracle(orc)
+    rng = np.random.default_rng(0x5EED0B0F + bd)
+    pw, ph, isz = 256, 64, 1 if bd == 8 else 2
+    dt = np.uint8 if bd == 8 else np.uint16
+    refs = [np.full((ph, pw), 1 << (bd - 1), dt) for _ in range(2)]
+    blocks = [(16 * i, 16 * (i % 3)) for i in range(15)]
+    for r in refs:
+        for (x, y) in blocks:
+            r[max(0, y - 4):y + 20, x + 10:x + 20] = rng.integers(0, 1 << bd, size=r[max(0, y - 4):y + 20, x + 10:x + 20].shape)
+    want = np.zeros((ph, pw), dt)
+    d_refs = [batch.DeviceBuffer.from_host(r) for r in refs]
+    d_out = batch.DeviceBuffer.from_host(want)
+    arr = (abi.BipredJob * len(blocks))()
+    for i, (x, y) in enumerate(blocks):
+        j = abi.BipredJob()
+        j.x, j.y, j.w, j.h, j.pic_w, j.pic_h, j.bdof, j.pred_flag = x, y, 16, 16, pw, ph, 1, 3
+        for k, v in enumerate((int(rng.integers(-3, 4)) * 16, 0, int(rng.integers(-3, 4)) * 16 + int(rng.integers(0, 16)), int(rng.integers(0, 16)))):
+            j.mv[k] = v
+        j.dst_stride = j.ref0_stride = j.ref1_stride = pw * isz
+        hj = abi.BipredJob.from_buffer_copy(j)
+        hj.dst, hj.ref0, hj.ref1 = P(want, y * pw + x), P(refs[0]), P(refs[1])
+        orc.orc_bipred_block(bd, ctypes.byref(hj))
+        j.dst, j.ref0, j.ref1 = d_out.ptr + (y * pw + x) * isz, d_refs[0].ptr, d_refs[1].ptr
+        arr[i] = j
+    d_jobs = batch.jobs_to_device(arr)
+    dev.vvc355_bipred_batch(None, bd, d_jobs.ptr, len(blocks))
+    dev.vvc355_stream_sync(None)
+    got = d_out.to_host(dt, want.shape)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, f"{len(bad)} samples differ, first at {bad[0].tolist()}"
+    # the case is not vacuous: the right-most sub-blocks are not plain averages
+    avg = ((refs[0].astype(np.int64) + refs[1] + 1) >> 1)
+    assert any(np.any(want[y:y + 16, x + 12:x + 16] != avg[y:y + 16, x + 12:x + 16]) for (x, y) in blocks)
