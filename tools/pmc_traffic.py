@@ -30,7 +30,10 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
     "deblock_horizontal": "deblock_frame_kernel",   # second one
     "sao": "sao_frame_kernel",
-    "alf": "alf_",                              # the stage driver's four kernels: build, luma, chroma, cc
+    "alf": "alf_",                              # the stage driver's kernels: the job builder and the CTB kernel (luma + chroma + CC-ALF)
+    "lmcs_chroma_residual_scale": "lmcs_chroma_resid_kernel",
+    "side_tables_fill": "tabfill_kernel",       # both launches of a step: the side tables and the inter stage's MvField table
+    "itx_job_build": "itx_build_kernel",
 }
 
 
@@ -52,7 +55,7 @@ def per_stage(directory, counter, n_passes):
         for r in sel:
             largest[r["Kernel_Name"]] = max(largest.get(r["Kernel_Name"], 0), int(r["Grid_Size"]))
         for r in sel:
-            if int(r["Grid_Size"]) == largest[r["Kernel_Name"]]:
+            if int(r["Grid_Size"]) == largest[r["Kernel_Name"]] or stage == "side_tables_fill":
                 by_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
         out[stage] = sum(sum(v) / len(v) for v in by_kernel.values())
     return out
