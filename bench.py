@@ -690,6 +690,10 @@ def build_chain(lib, torch, fr):
         itf.width, itf.height, itf.hs, itf.vs, itf.size_y = fr.width, fr.height, 1, 1, 64
         d_rjall = fr.upload(np.zeros(n_itx * ctypes.sizeof(abi.LmcsResidJob), np.uint8), per_frame=False) if (LMCS and chroma_first is not None) else None
         itf.resid_jobs = ptr(d_rjall) if d_rjall is not None else 0
+        # every 64x64 unit's chroma residual scale, one table per picture (vvc355_lmcs_vpdu_scale_pass); the residual jobs point into it
+        vux, vuy = (fr.width + 63) // 64, (fr.height + 63) // 64
+        d_vscale = fr.upload(np.zeros(vux * vuy, np.int16), per_frame=False) if d_rjall is not None else None
+        itf.scale_table = ptr(d_vscale) if d_vscale is not None else 0
         d_itf = fr.upload(np.frombuffer(bytes(itf), np.uint8))
         fr.keep.append(itf)
         d_itx.zero_()
@@ -766,6 +770,32 @@ def build_chain(lib, torch, fr):
                     bad += not np.array_equal(env.after[rec_ptrs[c]][y_:y_ + j.h, x_:x_ + j.w], blk)
                 return len(idx), bad
 
+            lsf = abi.LmcsScaleFrame()
+            d_vtabs = [fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)]
+            lsf.luma, lsf.scale, lsf.model, lsf.luma_stride = ptr(rec[0]), ptr(d_vscale), ptr(d_model), fr.pitch(rec[0])
+            lsf.slice_idx, lsf.ctb_to_col_bd, lsf.ctb_to_row_bd = (ptr(t) for t in d_vtabs)
+            lsf.width, lsf.height, lsf.ctb_width, lsf.ctb_log2, lsf.size_y = fr.width, fr.height, fr.ncx, int(np.log2(CTB)), 64
+            d_lsf = fr.upload(np.frombuffer(bytes(lsf), np.uint8))
+            fr.keep.append(lsf)
+
+            def check_vpdu_scale(fc, orc, env):
+                # the whole table against the oracle's on the same luma plane (units whose neighbours the in-order pass has yet to write
+                # hold a value nobody reads; they are compared all the same)
+                orc.orc_lmcs_vpdu_scale_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.LmcsScaleFrame)]
+                orc.orc_lmcs_vpdu_scale_pass.restype = None
+                luma_h = env.snap(rec[0])
+                want = np.zeros(vux * vuy, np.int16)
+                tabs = [np.ascontiguousarray(t) for t in (work.slice_idx, work.col_bd, work.row_bd)]
+                hf = abi.LmcsScaleFrame.from_buffer_copy(bytes(lsf))
+                hf.luma, hf.scale, hf.model = luma_h.ctypes.data, want.ctypes.data, ctypes.addressof(lmcs_model)
+                hf.slice_idx, hf.ctb_to_col_bd, hf.ctb_to_row_bd = (t.ctypes.data for t in tabs)
+                orc.orc_lmcs_vpdu_scale_pass(bd, ctypes.byref(hf))
+                got = env.after[ptr(d_vscale)].view(np.int16)[:vux * vuy]
+                return vux * vuy, int((got != want).sum())
+
+            chain.append(Stage("lmcs_vpdu_scale_table", f"lmcs_vpdu_scale_kernel<{bd}>",
+                               lambda st: lib.vvc355_lmcs_vpdu_scale_pass(st, bd, ptr(d_lsf), ctypes.addressof(lsf)),
+                               vux * vuy * (128 * isz + 2), writes=[d_vscale], check=check_vpdu_scale))
             n_cs = int(sum(len(x0c) * n * n for (_c, x0c, _y, n, _o) in cres))
             chain.append(Stage("lmcs_chroma_residual_scale", f"lmcs_chroma_resid_kernel<{bd}>",
                                lambda st: lib.vvc355_lmcs_chroma_resid_batch(st, bd, ptr(d_rjall), n_itx, ptr(d_model)),

@@ -120,6 +120,7 @@ BATCH_SIGNATURES = {
     "intra_pred_batch": ("v", "pipii"),
     "cclm_batch":       ("v", "pipi"),
     "lmcs_chroma_resid_batch": ("v", "pipip"),
+    "lmcs_vpdu_scale_pass": ("v", "pipp"),
     "pred_fused_batch": ("v", "pipi"),
     "bipred_batch":     ("v", "pipi"),
     "bipred_chroma_batch": ("v", "pipi"),
@@ -506,7 +507,16 @@ class ItxFrame(ctypes.Structure):
                 ("stride", ctypes.c_int32 * 3), ("n_tus", ctypes.c_int32),
                 ("range", ctypes.c_uint8), ("bd", ctypes.c_uint8), ("pixel_shift", ctypes.c_uint8), ("tu_flags", ctypes.c_uint8),
                 ("resid_jobs", ctypes.c_uint64), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
-                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("size_y", ctypes.c_uint8), ("pad_", ctypes.c_uint8)]
+                ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("size_y", ctypes.c_uint8), ("pad_", ctypes.c_uint8),
+                ("scale_table", ctypes.c_uint64)]
+
+
+class LmcsScaleFrame(ctypes.Structure):
+    """Mirror of vvc355_lmcs_scale_frame / orc_lmcs_scale_frame."""
+    _fields_ = [("luma", ctypes.c_uint64), ("scale", ctypes.c_uint64), ("model", ctypes.c_uint64), ("slice_idx", ctypes.c_uint64),
+                ("ctb_to_col_bd", ctypes.c_uint64), ("ctb_to_row_bd", ctypes.c_uint64),
+                ("luma_stride", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
+                ("ctb_log2", ctypes.c_uint8), ("size_y", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6)]
 
 
 class CuRec(ctypes.Structure):

@@ -1242,6 +1242,32 @@ __device__ __forceinline__ void resid_block_add(uint8_t *dst, int dst_stride, co
     }
 }
 
+// every 64x64 unit's scale: one wave per unit (vvc355_lmcs_vpdu_scale_pass)
+template <int BD>
+__global__ __launch_bounds__(256) void lmcs_vpdu_scale_kernel(const vvc355_lmcs_scale_frame *__restrict__ fp)
+{
+    using px_t = typename Px<BD>::type;
+    const vvc355_lmcs_scale_frame f = load_uniform(fp);
+    const int size = f.size_y, ux = (f.width + size - 1) / size, uy = (f.height + size - 1) / size;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= ux * uy)
+        return;
+    const int vy = u / ux, vx = u - vy * ux, x = vx * size, y = vy * size;
+    // ff_vvc_get_left / top_available(lc, x, y, 1, 0) for a unit's first sample: inside its CTU the neighbour unit precedes it; at the CTU's
+    // edge the neighbour CTU must exist in the same tile (and, above, the same slice): ff_vvc_decode_neighbour, vvc_ctu.c:2468-2495
+    const int ctb = 1 << f.ctb_log2, rx = x >> f.ctb_log2, ry = y >> f.ctb_log2, rs = ry * f.ctb_width + rx;
+    const int16_t *slice_idx = (const int16_t *)f.slice_idx, *col_bd = (const int16_t *)f.ctb_to_col_bd, *row_bd = (const int16_t *)f.ctb_to_row_bd;
+    bool avail_l = true, avail_t = true;
+    if ((x & (ctb - 1)) == 0)
+        avail_l = rx > 0 && gld<int16_t>(col_bd + rx) == gld<int16_t>(col_bd + rx - 1);
+    if ((y & (ctb - 1)) == 0)
+        avail_t = ry > 0 && gld<int16_t>(row_bd + ry) == gld<int16_t>(row_bd + ry - 1) && gld<int16_t>(slice_idx + rs) == gld<int16_t>(slice_idx + rs - f.ctb_width);
+    const int s = lmcs_scale_from_plane<BD>((const vvc355_lmcs_model *)f.model, (const uint8_t *)f.luma, f.luma_stride / (int)sizeof(px_t), x, y, size, avail_l, avail_t,
+                                            f.width, f.height, lane);
+    if (lane == 0)
+        gst<int16_t>((int16_t *)f.scale + u, (int16_t)s);
+}
+
 // One wave per chroma block: the 64x64 unit's scale from the luma plane, then the residual added to the block.
 template <int BD>
 __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmcs_resid_job *__restrict__ jobs, int n_jobs, const vvc355_lmcs_model *__restrict__ model)
@@ -1253,7 +1279,7 @@ __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmc
     const vvc355_lmcs_resid_job j = load_uniform(jobs + ji);
     if (j.w <= 0)
         return;                 // an empty slot of a job array the transform-block builder wrote (vvc355_itx_frame.resid_jobs)
-    const int scale = (j.joint & 8) ? lmcs_scale_from_plane<BD>(model, (const uint8_t *)j.luma, j.luma_stride / (int)sizeof(px_t), j.x_vpdu, j.y_vpdu, j.size_y,
+    const int scale = (j.joint & 16) ? (int)gld<int16_t>((const int16_t *)j.luma) : (j.joint & 8) ? lmcs_scale_from_plane<BD>(model, (const uint8_t *)j.luma, j.luma_stride / (int)sizeof(px_t), j.x_vpdu, j.y_vpdu, j.size_y,
                                                                 j.avail_l != 0, j.avail_t != 0, j.pic_w, j.pic_h, lane) : 0;
     resid_block_add<BD>((uint8_t *)j.dst, j.dst_stride, (const int *)j.resid, j.w, j.h, j.joint, scale, lane);
 }
@@ -1261,6 +1287,19 @@ __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmc
 } // namespace vvc355
 
 extern "C" {
+
+void vvc355_lmcs_vpdu_scale_pass(void *stream, int bd, const vvc355_lmcs_scale_frame *frame_dev, const vvc355_lmcs_scale_frame *frame_host)
+{
+    const int size = frame_host->size_y;
+    if (size != 32 && size != 64) {
+        fprintf(stderr, "vvc_mi355: vvc355_lmcs_vpdu_scale_pass: unit size %d (min(CtbSizeY, 64) is 32 or 64)\n", size);
+        abort();
+    }
+    const int n = ((frame_host->width + size - 1) / size) * ((frame_host->height + size - 1) / size);
+    if (n <= 0) return;
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((vvc355::lmcs_vpdu_scale_kernel<BD>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, frame_dev));
+    HIP_CHECK(hipGetLastError());
+}
 
 void vvc355_lmcs_chroma_resid_batch(void *stream, int bd, const vvc355_lmcs_resid_job *jobs_dev, int n_jobs, const vvc355_lmcs_model *model_dev)
 {

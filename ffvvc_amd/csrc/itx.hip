@@ -871,6 +871,11 @@ __global__ __launch_bounds__(256) void itx_build_kernel(const vvc355_itx_frame *
             r.pic_w = (int16_t)f.width; r.pic_h = (int16_t)f.height; r.size_y = f.size_y;
             r.avail_l = (t.flags >> 4) & 1; r.avail_t = (t.flags >> 5) & 1;
             r.joint = 8;
+            if (f.scale_table) {          // the unit's entry of vvc355_lmcs_vpdu_scale_pass's table instead of a derivation per block
+                const int ux = (f.width + f.size_y - 1) / f.size_y;
+                r.luma = f.scale_table + (uint64_t)((r.y_vpdu / f.size_y) * ux + r.x_vpdu / f.size_y) * 2;
+                r.joint = 8 | 16;
+            }
         }
         ((vvc355_lmcs_resid_job *)f.resid_jobs)[i] = r;
     }

@@ -321,6 +321,7 @@ typedef struct vvc355_itx_frame {
     uint64_t resid_jobs;
     int32_t  width, height;       /* luma picture size */
     uint8_t  hs, vs, size_y, pad_;      /* chroma shifts; min(CtbSizeY, 64) */
+    uint64_t scale_table;         /* 0, or vvc355_lmcs_scale_frame.scale: the residual jobs then take their scale from it (joint bit 4) */
 } vvc355_itx_frame;
 void vvc355_itx_frame_build(void *stream, const vvc355_itx_frame *frame_dev, const vvc355_itx_frame *frame_host);
 
@@ -456,7 +457,8 @@ typedef struct vvc355_lmcs_model {
  * vvc355_recon_frame_pass (joint bit 3), which orders it.
  *   x_vpdu, y_vpdu   (cu->x0, cu->y0) & ~(size_y - 1), luma samples; size_y = min(CtbSizeY, 64); pic_w, pic_h luma picture size
  *   avail_l/_t       ff_vvc_get_left_available / _top_available(lc, x_vpdu, y_vpdu, 1, 0) != 0 (picture, slice, tile borders)
- *   joint            as vvc355_recon_cmd.joint (bit 0 joint residual, bit 1 negative sign, bit 2 shift; bit 3 = scale, 0 = plain add)
+ *   joint            as vvc355_recon_cmd.joint (bit 0 joint residual, bit 1 negative sign, bit 2 shift; bit 3 = scale, 0 = plain add);
+ *                    bit 4 (with bit 3): the scale is read from vvc355_lmcs_vpdu_scale_pass's table — `luma` is the address of the unit's entry
  */
 typedef struct vvc355_lmcs_resid_job {
     uint64_t dst;                 /* DEVICE: the block in its chroma plane */
@@ -469,6 +471,24 @@ typedef struct vvc355_lmcs_resid_job {
     uint8_t  pad_[7];
 } vvc355_lmcs_resid_job;
 void vvc355_lmcs_chroma_resid_batch(void *stream, int bd, const vvc355_lmcs_resid_job *jobs_dev, int n_jobs, const vvc355_lmcs_model *model_dev);
+
+/*
+ * The chroma residual scale of every 64x64 unit of a picture in one launch (lmcs_derive_chroma_scale, vvc_intra_template.c:390-429, for all
+ * units at once): int16 scale[unit row][unit column] from the reconstructed luma plane, neighbour availability from the slice / tile maps
+ * the way ff_vvc_decode_neighbour sets ctb_left_flag / ctb_up_flag (vvc_ctu.c:2468-2495).  Jobs of vvc355_lmcs_chroma_resid_batch with
+ * joint bit 4 take their scale from this table (job.luma = DEVICE address of the unit's entry) instead of deriving it per block — valid for
+ * the same blocks as the batch entry itself (units whose neighbours are final when this pass runs).
+ */
+typedef struct vvc355_lmcs_scale_frame {
+    uint64_t luma;                /* DEVICE: sample (0, 0) of the luma plane */
+    uint64_t scale;               /* DEVICE int16[units_y][units_x] (output), units_x = ceil(width / size_y) */
+    uint64_t model;               /* DEVICE vvc355_lmcs_model */
+    uint64_t slice_idx, ctb_to_col_bd, ctb_to_row_bd;      /* int16 per CTB / per CTB column (+1) / per CTB row (+1) */
+    int32_t  luma_stride;         /* bytes */
+    int32_t  width, height, ctb_width;
+    uint8_t  ctb_log2, size_y, pad_[6];
+} vvc355_lmcs_scale_frame;
+void vvc355_lmcs_vpdu_scale_pass(void *stream, int bd, const vvc355_lmcs_scale_frame *frame_dev, const vvc355_lmcs_scale_frame *frame_host);
 /* synchronous forms: plane addresses are HOST addresses; pic_w/pic_h (luma samples) bound what is staged */
 void vvc355_intra_cclm_pred_flat(int bd, const vvc355_cclm_job *job, int pic_w, int pic_h);
 void vvc355_lmcs_scale_chroma_flat(int bd, const vvc355_lmcs_scale_job *job, int *dst, const int *coeff, int width, int height);

@@ -348,7 +348,13 @@ ORC_API void orc_lmcs_chroma_resid_block(int bd, const orc_lmcs_resid_job *j, co
     memcpy(tmp, res, sizeof(int) * n);
     if (j->joint & 1)
         orc_pred_residual_joint(tmp, j->w, j->h, (j->joint & 2) ? -1 : 1, (j->joint >> 2) & 1);
-    if (j->joint & 8) {
+    if (j->joint & 16) {
+        const int scale = *(const int16_t *)(uintptr_t)j->luma;           /* the unit's entry of orc_lmcs_vpdu_scale_pass's table */
+        for (int i = 0; i < n; i++) {
+            const int v = orc_clip_intp2(tmp[i], bd);
+            tmp[i] = v > 0 ? (v * scale + (1 << 10)) >> 11 : -((-v * scale + (1 << 10)) >> 11);
+        }
+    } else if (j->joint & 8) {
         orc_lmcs_scale_job sj;
         memset(&sj, 0, sizeof(sj));
         sj.luma = j->luma; sj.luma_stride = j->luma_stride;
@@ -405,4 +411,30 @@ ORC_API void orc_tab_fill_pass(const orc_tab_fill *f)
             for (int x = mv[i].x0 >> 2; x < (mv[i].x0 + mv[i].w) >> 2; x++)
                 memcpy(TAB(uint8_t, f->mvf) + (size_t)(y * f->mvf_pitch + x) * 24, mv[i].mvf, 24);
 #undef TAB
+}
+
+/* lmcs_derive_chroma_scale (vvc_intra_template.c:390-429) for every 64x64 unit of the picture; a unit's first sample has a left / upper
+ * neighbour inside its CTU always (an earlier unit), at the CTU's edge when ff_vvc_decode_neighbour (vvc_ctu.c:2468-2495) sets
+ * ctb_left_flag / ctb_up_flag — what ff_vvc_get_left / top_available(lc, x, y, 1, 0) return there */
+ORC_API void orc_lmcs_vpdu_scale_pass(int bd, const orc_lmcs_scale_frame *f)
+{
+    const orc_lmcs_model *m = (const orc_lmcs_model *)(uintptr_t)f->model;
+    const int16_t *slice_idx = (const int16_t *)(uintptr_t)f->slice_idx;
+    const int16_t *col_bd = (const int16_t *)(uintptr_t)f->ctb_to_col_bd, *row_bd = (const int16_t *)(uintptr_t)f->ctb_to_row_bd;
+    int16_t *out = (int16_t *)(uintptr_t)f->scale;
+    const int size = f->size_y, ux = (f->width + size - 1) / size, uy = (f->height + size - 1) / size, ctb = 1 << f->ctb_log2;
+    for (int vy = 0; vy < uy; vy++)
+        for (int vx = 0; vx < ux; vx++) {
+            const int x = vx * size, y = vy * size, rx = x >> f->ctb_log2, ry = y >> f->ctb_log2, rs = ry * f->ctb_width + rx;
+            orc_lmcs_scale_job sj;
+            memset(&sj, 0, sizeof(sj));
+            sj.luma = f->luma; sj.luma_stride = f->luma_stride;
+            sj.x_vpdu = (int16_t)x; sj.y_vpdu = (int16_t)y; sj.pic_w = (int16_t)f->width; sj.pic_h = (int16_t)f->height; sj.size_y = (int16_t)size;
+            sj.avail_l = (x & (ctb - 1)) ? 1 : (rx > 0 && col_bd[rx] == col_bd[rx - 1]);
+            sj.avail_t = (y & (ctb - 1)) ? 1 : (ry > 0 && row_bd[ry] == row_bd[ry - 1] && slice_idx[rs] == slice_idx[rs - f->ctb_width]);
+            sj.min_bin_idx = m->min_bin_idx; sj.max_bin_idx = m->max_bin_idx;
+            memcpy(sj.pivot, m->pivot, sizeof(sj.pivot));
+            memcpy(sj.chroma_scale_coeff, m->chroma_scale_coeff, sizeof(sj.chroma_scale_coeff));
+            out[vy * ux + vx] = (int16_t)orc_lmcs_chroma_scale_flat(bd, &sj);
+        }
 }

@@ -381,6 +381,13 @@ typedef struct orc_lmcs_resid_job {
     uint8_t  avail_l, avail_t, joint, pad_[7];
 } orc_lmcs_resid_job;
 void orc_lmcs_chroma_resid_block(int bd, const orc_lmcs_resid_job *job, const orc_lmcs_model *model);
+/* same layout as vvc355_lmcs_scale_frame: the chroma residual scale of every 64x64 unit (lmcs_derive_chroma_scale for all units) */
+typedef struct orc_lmcs_scale_frame {
+    uint64_t luma, scale, model, slice_idx, ctb_to_col_bd, ctb_to_row_bd;
+    int32_t  luma_stride, width, height, ctb_width;
+    uint8_t  ctb_log2, size_y, pad_[6];
+} orc_lmcs_scale_frame;
+void orc_lmcs_vpdu_scale_pass(int bd, const orc_lmcs_scale_frame *f);
 void orc_recon_debug_job(const orc_recon_frame *f, int rs, int k, orc_intra_job *out);
 
 #ifdef __cplusplus

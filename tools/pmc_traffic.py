@@ -32,6 +32,7 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "sao": "sao_frame_kernel",
     "alf": "alf_",                              # the stage driver's kernels: the job builder and the CTB kernel (luma + chroma + CC-ALF)
     "lmcs_chroma_residual_scale": "lmcs_chroma_resid_kernel",
+    "lmcs_vpdu_scale_table": "lmcs_vpdu_scale_kernel",
     "side_tables_fill": "tabfill_kernel",       # both launches of a step: the side tables and the inter stage's MvField table
     "itx_job_build": "itx_build_kernel",
 }
