@@ -890,7 +890,12 @@ def build_chain(lib, torch, fr):
     # what earlier blocks wrote, then the residual), CTUs released in wavefront order
     if len(work.order):
         cmds_dev = work.bind(ptr(res), ptr(d_ciip), isz)
-        d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(work.order)
+        # ticket order: longest remaining dependency chain first (host helper of the C ABI; the oracle walks in raster = decoding order)
+        ticket_order = np.zeros(fr.n_ctus, np.int32)
+        n_tk = lib.vvc355_recon_order(np.ascontiguousarray(work.ctus).ctypes.data, fr.ncx, fr.ncy, ticket_order.ctypes.data)
+        assert n_tk == len(work.order)
+        ticket_order = ticket_order[:n_tk].copy() if not os.environ.get("VVC355_RECON_RASTER") else work.order
+        d_cmds, d_ctus, d_order = fr.upload(cmds_dev.view(np.uint8)), fr.upload(work.ctus.view(np.uint8)), fr.upload(ticket_order)
         d_rstate = fr.upload(np.zeros(lib.vvc355_recon_state_bytes(fr.n_ctus), np.uint8), per_frame=False)
         d_rslice, d_rcol, d_rrow = fr.upload(work.slice_idx), fr.upload(work.col_bd), fr.upload(work.row_bd)
         rf = work.frame(rec_ptrs, pitches, ptr(d_cmds), ptr(d_ctus), ptr(d_order), ptr(d_rstate), ptr(d_rslice), ptr(d_rcol), ptr(d_rrow),
@@ -913,6 +918,8 @@ def build_chain(lib, torch, fr):
             env.mirror.add(ptr(d_cmds), hc.view(np.uint8))
             f = fc.translate(rf, env.mirror, ("plane", "cmds", "ctus", "order", "slice_idx", "ctb_to_col_bd", "ctb_to_row_bd") + (("lmcs_model",) if LMCS else ()))
             f.state = 0
+            raster_order = np.ascontiguousarray(work.order)
+            f.order = raster_order.ctypes.data
             orc.orc_recon_frame_pass(bd, ctypes.byref(f))
             bad = sum(int(not np.array_equal(w_, env.after[p_])) for p_, w_ in zip(rec_ptrs, work_p))
             env.stats["recon_commands"] = int(len(work.cmds))
@@ -925,15 +932,22 @@ def build_chain(lib, torch, fr):
         ncx_ = fr.ncx if hasattr(fr, "ncx") else (fr.width + CTB - 1) // CTB
         ncmd = work.ctus["n_cmd"].astype(np.int64)
         depth_c, depth_k = np.zeros(len(ncmd), np.int64), np.zeros(len(ncmd), np.int64)
+        cflags = work.ctus["flags"].astype(np.int64)
         for rs in work.order:
             rs = int(rs)
             rx_, best_c, best_k = rs % ncx_, 0, 0
-            for d_ in ((rs - 1) if rx_ else -1, (rs - ncx_ - 1) if rx_ else -1, rs - ncx_, (rs - ncx_ + 1) if rx_ + 1 < ncx_ else -1):
+            if cflags[rs] & abi.RECON_CTU_LIGHT:      # waits for the luma of the flagged neighbours only
+                deps_ = ((rs - 1) if (rx_ and cflags[rs] & abi.RECON_CTU_LUMA_LEFT) else -1, (rs - ncx_) if cflags[rs] & abi.RECON_CTU_LUMA_UP else -1)
+            else:
+                deps_ = ((rs - 1) if rx_ else -1, (rs - ncx_ - 1) if rx_ else -1, rs - ncx_, (rs - ncx_ + 1) if rx_ + 1 < ncx_ else -1)
+            for d_ in deps_:
                 if d_ >= 0 and ncmd[d_]:
                     best_c, best_k = max(best_c, int(depth_c[d_])), max(best_k, int(depth_k[d_]))
-            depth_c[rs], depth_k[rs] = best_c + 1, best_k + int(ncmd[rs])
+            light_ = bool(cflags[rs] & abi.RECON_CTU_LIGHT)
+            depth_c[rs], depth_k[rs] = best_c + (0 if light_ else 1), best_k + (int(ncmd[rs]) + 3) // 4 if light_ else best_k + int(ncmd[rs])
         recon_chain = {"ctus_with_commands": int(len(work.order)), "commands": int(len(work.cmds)),
-                       "longest_dependency_chain_ctus": int(depth_c.max()), "longest_dependency_chain_commands": int(depth_k.max())}
+                       "longest_dependency_chain_ctus": int(depth_c.max()), "longest_dependency_chain_commands": int(depth_k.max()),
+                       "chain_note": "chains follow what the pass waits for (LIGHT CTUs: flagged luma neighbours only, weighted a quarter); tickets in vvc355_recon_order() order"}
         chain.append(Stage("intra_recon_wavefront", f"recon_wavefront_kernel<{bd}>", lambda st: lib.vvc355_recon_frame_pass(st, bd, ptr(d_rf), ctypes.addressof(rf)),
                            intra_samples * isz, writes=rec, check=check_recon))
         chain[-1].extra = {"bound": "dependency chain (one wave per CTU and channel type), not bandwidth", **recon_chain}

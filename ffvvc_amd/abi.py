@@ -136,6 +136,7 @@ BATCH_SIGNATURES = {
     "lfnst_batch":      ("v", "ppi"),
     "recon_frame_pass": ("v", "pipp"),
     "recon_state_bytes": ("z", "i"),
+    "recon_order":      ("i", "piip"),
     "tab_fill_pass":    ("v", "ppp"),
     "itx_frame_build":  ("v", "ppp"),
 }

@@ -26,7 +26,11 @@ __device__ __forceinline__ unsigned long long *rprof_lds() { __shared__ unsigned
 #define RPROF_NOW() wall_clock64()
 #define RPROF_ADD(slot, t0) do { unsigned long long *p_ = rprof_lds(); p_[slot] = p_[slot] + (unsigned long long)(wall_clock64() - (t0)); } while (0)
 #define RPROF_INC(slot) do { unsigned long long *p_ = rprof_lds(); p_[slot] = p_[slot] + 1ull; } while (0)
+// per-CTU timeline: [rs][8] wall-clock stamps (0 ticket, 1 luma wait over, 2 luma flag up, 3 chroma wait over, 4 chroma walk over, 5 done flag up, 6 flags | n_cmd << 8, 7 ticket)
+__device__ unsigned long long vvc355_recon_trace[4096 * 8];
+#define RTRACE(rs, slot, v) do { vvc355_recon_trace[((rs) & 4095) * 8 + (slot)] = (unsigned long long)(v); } while (0)
 #else
+#define RTRACE(rs, slot, v) do { } while (0)
 #define RPROF_NOW() 0ull
 #define RPROF_ADD(slot, t0) do { (void)(t0); } while (0)
 #define RPROF_INC(slot) do { } while (0)
@@ -1613,6 +1617,7 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
     using px_t = typename Px<BD>::type;
     const int ncx = f.ctb_width, n_ctus = ncx * f.ctb_height, ctb = 1 << f.ctb_log2, size_y = min(ctb, 64);
     if (role == 0) {
+        RTRACE(rs, 0, wall_clock64());
         const int dep[2] = { ((ctu.flags & VVC355_RECON_CTU_LUMA_LEFT) && rx > 0) ? rs - 1 : -1, ((ctu.flags & VVC355_RECON_CTU_LUMA_UP) && ry > 0) ? rs - ncx : -1 };
 #pragma unroll
         for (int d = 0; d < 2; d++) {
@@ -1623,6 +1628,7 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RTRACE(rs, 1, wall_clock64()); RTRACE(rs, 3, wall_clock64());
     }
     __syncthreads();
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
@@ -1660,6 +1666,8 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&state[kReconFlags + n_ctus + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RTRACE(rs, 2, wall_clock64()); RTRACE(rs, 4, wall_clock64()); RTRACE(rs, 5, wall_clock64());
+        RTRACE(rs, 6, ctu.flags | ((unsigned long long)ctu.n_cmd << 8)); 
     }
 }
 
@@ -1704,6 +1712,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         cx.ctb_up_left = cx.ctb_left && cx.ctb_up;
         cx.ox = rx * ctb; cx.oy = ry * ctb;
     }
+    RTRACE(rs, 7, ticket | ((unsigned long long)blockIdx.x << 32));
     if (ctu.flags & VVC355_RECON_CTU_LIGHT) {          // workgroup-uniform
         recon_light_ctu<BD>(f, ctu, cx, state, rs, rx, ry, role, tid);
         return true;
@@ -1738,6 +1747,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     // chroma wave the whole neighbour.  From here to the join at the end the two waves run on their own: each waits, loads its own edges
     // and walks its commands; where the chroma wave reads luma (CCLM, the chroma residual scale) it synchronises on luma_done.
     const unsigned long long t_wait = RPROF_NOW();
+    if (role == 0) { RTRACE(rs, 0, wall_clock64()); RTRACE(rs, 6, ctu.flags | ((unsigned long long)ctu.n_cmd << 8)); }
     {
         const int n_ctus = ncx * f.ctb_height;
         const int dep[4] = { rx > 0 ? rs - 1 : -1, (rx > 0 && ry > 0) ? rs - ncx - 1 : -1, ry > 0 ? rs - ncx : -1, (ry > 0 && rx + 1 < ncx) ? rs - ncx + 1 : -1 };
@@ -1756,6 +1766,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     }
     RPROF_ADD(1 + 32 * role, t_wait);
     RPROF_INC(0 + 32 * role);
+    RTRACE(rs, role ? 3 : 1, wall_clock64());
     const unsigned long long t_load = RPROF_NOW();
     if constexpr (TILE) {
         // what the neighbours wrote: left apron and the rows above
@@ -2038,6 +2049,9 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&state[kReconFlags + ncx * f.ctb_height + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RTRACE(rs, 2, wall_clock64());
+    } else {
+        RTRACE(rs, 4, wall_clock64());
     }
     const unsigned long long t_join = RPROF_NOW();
     __syncthreads();
@@ -2066,6 +2080,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&state[kReconFlags + rs], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RTRACE(rs, 5, wall_clock64());
     }
     if constexpr (TILE) {
 #pragma unroll
@@ -2137,6 +2152,10 @@ void vvc355_recon_prof_read(unsigned long long *out, int reset)
     HIP_CHECK(hipDeviceGetAttribute(&ckhz, hipDeviceAttributeClockRate, dev));
     out[63] = (unsigned long long)khz;
     out[62] = (unsigned long long)ckhz;
+    if (reset == 2) {       // out: 4096 * 8 stamps
+        HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(vvc355::vvc355_recon_trace), sizeof(unsigned long long) * 4096 * 8));
+        return;
+    }
     if (reset) {
         unsigned long long z[64] = {};
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vvc355::vvc355_recon_prof), z, sizeof(z)));

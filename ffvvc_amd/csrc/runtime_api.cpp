@@ -1,4 +1,9 @@
 // Runtime helper entries of the C ABI (device memory, streams) — see include/vvc_mi355.h.
+#include <algorithm>
+#include <queue>
+#include <utility>
+#include <vector>
+
 #include "runtime.hpp"
 #include "../../include/vvc_mi355.h"
 
@@ -54,6 +59,70 @@ void *vvc355_graph_end(void *stream)
 }
 void vvc355_graph_launch(void *graph_exec, void *stream) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream)); }
 void vvc355_graph_destroy(void *graph_exec) { HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec)); }
+// ---- vvc355_recon_order: critical-path-first ticket order of the in-order pass (host only; see include/vvc_mi355.h)
+namespace {
+// the CTUs `rs` waits for, as recon_one_ctu / recon_light_ctu (intra.hip) do: neighbours that have commands
+inline int recon_deps(const vvc355_recon_ctu *ctus, int ncx, int rs, int out[4])
+{
+    const int ry = rs / ncx, rx = rs - ry * ncx;
+    int n = 0;
+    auto take = [&](int d) { if (ctus[d].n_cmd) out[n++] = d; };
+    if (ctus[rs].flags & VVC355_RECON_CTU_LIGHT) {
+        if ((ctus[rs].flags & VVC355_RECON_CTU_LUMA_LEFT) && rx > 0) take(rs - 1);
+        if ((ctus[rs].flags & VVC355_RECON_CTU_LUMA_UP) && ry > 0) take(rs - ncx);
+        return n;
+    }
+    if (rx > 0) take(rs - 1);
+    if (rx > 0 && ry > 0) take(rs - ncx - 1);
+    if (ry > 0) take(rs - ncx);
+    if (ry > 0 && rx + 1 < ncx) take(rs - ncx + 1);
+    return n;
+}
+} // namespace
+
+int vvc355_recon_order(const vvc355_recon_ctu *ctus, int ncx, int ncy, int32_t *order)
+{
+    const int n = ncx * ncy;
+    if (n <= 0)
+        return 0;
+    std::vector<int64_t> tail(n, 0);       // weight of the heaviest chain that starts at the CTU (itself included)
+    std::vector<int> indeg(n, 0);
+    int dep[4];
+    std::vector<int64_t> below(n, 0);      // ... of the CTUs waiting for it
+    for (int rs = n - 1; rs >= 0; rs--) {  // a CTU's successors have larger raster indices: below[rs] is final here
+        if (!ctus[rs].n_cmd)
+            continue;
+        tail[rs] = ((ctus[rs].flags & VVC355_RECON_CTU_LIGHT) ? (ctus[rs].n_cmd + 3) / 4 : ctus[rs].n_cmd) + below[rs];
+        const int nd = recon_deps(ctus, ncx, rs, dep);
+        indeg[rs] = nd;
+        for (int i = 0; i < nd; i++)
+            below[dep[i]] = std::max(below[dep[i]], tail[rs]);
+    }
+    using Item = std::pair<int64_t, int>;   // (tail, -rs): heaviest first, raster order among equals
+    std::priority_queue<Item> ready;
+    for (int rs = 0; rs < n; rs++)
+        if (ctus[rs].n_cmd && !indeg[rs])
+            ready.push({ tail[rs], -rs });
+    int n_work = 0;
+    while (!ready.empty()) {
+        const int rs = -ready.top().second;
+        ready.pop();
+        order[n_work++] = rs;
+        const int ry = rs / ncx, rx = rs - ry * ncx;
+        const int succ[4] = { rx + 1 < ncx ? rs + 1 : -1, (ry + 1 < ncy && rx > 0) ? rs + ncx - 1 : -1, ry + 1 < ncy ? rs + ncx : -1,
+                              (ry + 1 < ncy && rx + 1 < ncx) ? rs + ncx + 1 : -1 };
+        for (int s : succ) {
+            if (s < 0 || !ctus[s].n_cmd)
+                continue;
+            const int nd = recon_deps(ctus, ncx, s, dep);
+            for (int i = 0; i < nd; i++)
+                if (dep[i] == rs && --indeg[s] == 0)
+                    ready.push({ tail[s], -s });
+        }
+    }
+    return n_work;
+}
+
 const char *vvc355_version(void) { return "vvc_mi355 0.1 (gfx950)"; }
 
 } // extern "C"

@@ -938,7 +938,9 @@ typedef struct vvc355_recon_ctu { uint32_t first_cmd, n_cmd, flags; } vvc355_rec
 typedef struct vvc355_recon_frame {
     uint64_t plane[3];            /* component planes, predicted / reconstructed in place */
     uint64_t cmds, ctus;          /* vvc355_recon_cmd[], vvc355_recon_ctu per CTU (raster order; n_cmd = 0: nothing to do) */
-    uint64_t order;               /* int32 raster indices of the CTUs that have commands, ascending; n_work entries */
+    uint64_t order;               /* int32 raster indices of the CTUs that have commands, n_work entries, every CTU after the CTUs it waits for
+                                   * (see flags above): ascending raster order qualifies; vvc355_recon_order() gives the order that keeps
+                                   * the longest dependency chains moving */
     uint64_t state;               /* DEVICE scratch of vvc355_recon_state_bytes(): ticket counter + per-CTU done flags */
     uint64_t slice_idx, ctb_to_col_bd, ctb_to_row_bd;    /* int16 per CTB / per CTB column (+1) / per CTB row (+1) */
     int32_t  stride[3];           /* bytes */
@@ -950,6 +952,14 @@ typedef struct vvc355_recon_frame {
     uint64_t lmcs_model;          /* 0, or DEVICE vvc355_lmcs_model: the picture's LMCS model for RESID commands with joint bit 3 (chroma residual scaling) */
 } vvc355_recon_frame;
 size_t vvc355_recon_state_bytes(int n_ctus);
+/*
+ * HOST helper: the ticket order of a picture's CTUs (vvc355_recon_frame.order) from the per-CTU table, no device work.  Workgroups take
+ * CTUs in this order and hold their slot while they wait for neighbours, so raster order lets the workgroups pile up behind the first
+ * unfinished chain while CTUs further down that wait for nothing are not started.  This is list scheduling, longest remaining chain first:
+ * a CTU's weight = its commands (a quarter for LIGHT CTUs) + the heaviest chain of CTUs waiting for it; among the CTUs whose predecessors
+ * are all placed the heaviest goes next.  Returns n_work (the CTUs with commands); order has room for ctb_width * ctb_height entries.
+ */
+int vvc355_recon_order(const vvc355_recon_ctu *ctus_host, int ctb_width, int ctb_height, int32_t *order_host);
 void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *frame_dev, const vvc355_recon_frame *frame_host);
 
 #ifdef __cplusplus

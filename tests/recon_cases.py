@@ -191,3 +191,11 @@ class ReconWork:
         f.ctb_log2, f.hs, f.vs, f.wpp, f.collocated = self.ctb_log2, self.hs, self.vs, wpp, collocated
         f.lmcs_model = lmcs_ptr
         return f
+
+
+def critical_order(lib, ctus, ncx, ncy):
+    """vvc355_recon_order (host helper of the C ABI): the ticket order that keeps the longest dependency chains moving."""
+    out = np.zeros(ncx * ncy, np.int32)
+    table = np.ascontiguousarray(ctus)
+    n = lib.vvc355_recon_order(table.ctypes.data, ncx, ncy, out.ctypes.data)
+    return out[:n].copy()

@@ -15,12 +15,16 @@ from ffvvc_amd import abi, batch
 pytestmark = pytest.mark.gpu
 
 
-def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
+def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, ticket_order="raster", **kw):
     orc.orc_recon_frame_pass.argtypes = [ctypes.c_int, ctypes.POINTER(abi.ReconFrame)]
     orc.orc_recon_frame_pass.restype = None
     hs, vs = fmt
     isz = 1 if bd == 8 else 2
     work = recon_cases.ReconWork(rng, w, h, ctb_log2, hs, vs, **kw)
+    raster = work.order                  # the oracle walks the CTUs in decoding order whatever order the device takes its tickets in
+    if ticket_order == "critical":
+        work.order = recon_cases.critical_order(dev, work.ctus, work.ncx, work.ncy)
+        assert sorted(work.order.tolist()) == raster.tolist()
     model = recon_cases.ReconWork.lmcs_model(np.random.default_rng(0x1A5C + bd), bd) if kw.get("lmcs") else None
     d_model = batch.DeviceBuffer.from_host(np.frombuffer(bytes(model), np.uint8)) if model is not None else None
     dims = [(w, h), (w >> hs, h >> vs), (w >> hs, h >> vs)]
@@ -30,7 +34,7 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, **kw):
     # oracle on host copies
     want = [p.copy() for p in planes]
     hc = work.bind(resid.ctypes.data, inter.ctypes.data, isz)
-    hf = work.frame([P(p) for p in want], [d[0] * isz for d in dims], hc.ctypes.data, work.ctus.ctypes.data, work.order.ctypes.data, 0,
+    hf = work.frame([P(p) for p in want], [d[0] * isz for d in dims], hc.ctypes.data, work.ctus.ctypes.data, raster.ctypes.data, 0,
                     work.slice_idx.ctypes.data, work.col_bd.ctypes.data, work.row_bd.ctypes.data, wpp=kw.get("n_slices", 1) > 2, collocated=int(rng.integers(0, 2)),
                     lmcs_ptr=ctypes.addressof(model) if model is not None else 0)
     orc.orc_recon_frame_pass(bd, ctypes.byref(hf))
@@ -71,24 +75,42 @@ def test_recon_all_intra_wavefront(dev, orc, bd, fmt, ctb_log2):
     assert changed > 456 * 264 // 2
 
 
+@pytest.mark.parametrize("ticket_order", ["raster", "critical"])
 @pytest.mark.parametrize("bd", [10])
-def test_recon_mixed_picture(dev, orc, bd):
+def test_recon_mixed_picture(dev, orc, bd, ticket_order):
     """Inter and intra coding units mixed, whole CTUs without intra work among them (those are skipped by the scheduler)."""
     rng = np.random.default_rng(0x5EED0E77)
     intra_ctu = rng.random(12 * 7) < 0.4
-    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_frac=0.5, intra_ctu=None, ciip_frac=0.3)
+    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), ticket_order, intra_frac=0.5, intra_ctu=None, ciip_frac=0.3)
     assert 0 < len(work.order) <= 12 * 7 and (work.cmds["kind"] == abi.RECON_CIIP).sum() > 20
-    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), intra_ctu=intra_ctu)
+    work, changed = run_case(dev, orc, rng, bd, 1480, 840, 7, (1, 1), ticket_order, intra_ctu=intra_ctu)
     assert 0 < len(work.order) < 12 * 7
 
 
-def test_recon_more_ctus_than_workgroups(dev, orc):
+@pytest.mark.parametrize("ticket_order", ["raster", "critical"])
+def test_recon_more_ctus_than_workgroups(dev, orc, ticket_order):
     """4:2:0 with 32x32 CTUs on a picture of 576 CTUs: the LDS-tile path with the smallest CTU size, and more CTUs than the pass has
     persistent workgroups (256), so every workgroup walks several CTUs and waits on flags raised by workgroups that took later and
-    earlier tickets."""
+    earlier tickets — in raster order and in the order of vvc355_recon_order (tickets then jump between CTU rows)."""
     rng = np.random.default_rng(0x5EED0E99)
-    work, changed = run_case(dev, orc, rng, 10, 1024, 576, 5, (1, 1), intra_frac=1.0, n_slices=2)
+    work, changed = run_case(dev, orc, rng, 10, 1024, 576, 5, (1, 1), ticket_order, intra_frac=1.0, n_slices=2)
     assert len(work.order) == 32 * 18 and changed > 1024 * 576 // 2
+    if ticket_order == "critical":
+        assert not np.array_equal(work.order, np.sort(work.order))
+
+
+def test_recon_ticket_order_sparse_intra_clusters(dev, orc):
+    """A picture larger than the pass's 256 workgroups can hold at once (2040 CTUs of 32x32), a fifth of its CTUs intra in clusters, the rest
+    LIGHT: the critical-path-first order sends workgroups to clusters far down the picture while the first ones are still waiting."""
+    rng = np.random.default_rng(0x5EED0E9A)
+    w, h = 1920, 1088
+    ncx, ncy = w // 32, h // 32
+    seeds = rng.random((ncy, ncx)) < 0.05
+    intra_ctu = seeds.copy()
+    intra_ctu[:, 1:] |= seeds[:, :-1]
+    intra_ctu[1:, :] |= seeds[:-1, :]
+    work, changed = run_case(dev, orc, rng, 10, w, h, 5, (1, 1), "critical", intra_ctu=intra_ctu.reshape(-1), lmcs=True, resid_ctu=~intra_ctu.reshape(-1), coded_p=0.6)
+    assert len(work.order) > 1000 and not np.array_equal(work.order, np.sort(work.order))
 
 
 @pytest.mark.parametrize("bd,fmt,min_cu", [(10, (0, 0), 4), (8, (1, 1), 8), (12, (1, 0), 8)])
@@ -128,7 +150,7 @@ def test_recon_lmcs_light_ctus(dev, orc, bd, ctb_log2, w, h):
     ctb = 1 << ctb_log2
     n_ctb = ((w + ctb - 1) // ctb) * ((h + ctb - 1) // ctb)
     intra_ctu = rng.random(n_ctb) < 0.3
-    work, changed = run_case(dev, orc, rng, bd, w, h, ctb_log2, (1, 1), intra_ctu=intra_ctu, lmcs=True, resid_ctu=~intra_ctu, coded_p=0.8)
+    work, changed = run_case(dev, orc, rng, bd, w, h, ctb_log2, (1, 1), "critical" if bd == 10 else "raster", intra_ctu=intra_ctu, lmcs=True, resid_ctu=~intra_ctu, coded_p=0.8)
     fl = work.ctus["flags"]
     assert ((fl & abi.RECON_CTU_LIGHT) != 0).sum() > n_ctb // 3 and ((fl & abi.RECON_CTU_LUMA_LEFT) != 0).sum() > 2 and ((fl & abi.RECON_CTU_LUMA_UP) != 0).sum() > 2
     assert (fl[work.ctus["n_cmd"] > 0] == 0).sum() > 2
