@@ -44,6 +44,7 @@ DEBLOCK_JOBS = False           # deblocking through the stage driver (edge param
 AFFINE_FRAC = 0.06             # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF on both lists); --affine-frac
 GPM_FRAC = 0.05                # fraction of the regular inter blocks coded as geometric partitions (two uni-predictions + mask blend)
 CIIP_FRAC = 0.02               # fraction of the CTUs whose coding units are combined inter / intra (inter prediction aside, planar intra + blend in RECON)
+RECON_FRAMES = []              # the host copies of every picture's vvc355_recon_frame (the launch reads its grid hint from them)
 LMCS = True                    # sh_lmcs_used_flag + ph_chroma_residual_scale_flag on: forward luma map on the inter prediction, chroma residual scaling (--no-lmcs)
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -902,6 +903,7 @@ def build_chain(lib, torch, fr):
                         lmcs_ptr=ptr(d_model) if LMCS else 0)
         d_rf = fr.upload(np.frombuffer(bytes(rf), np.uint8))
         fr.keep.append(rf)
+        RECON_FRAMES.append(rf)
         n_pred = int((work.cmds["kind"] == abi.RECON_PRED).sum() + (work.cmds["kind"] == abi.RECON_CCLM).sum())
         intra_px = int(((work.cmds["kind"] == abi.RECON_MARK) & (work.cmds["c_idx"] == 0) * 1).astype(bool).sum())    # noqa: F841
 
@@ -1867,9 +1869,17 @@ def main(argv=None):
     def barrier():
         sharding.barrier(dist, world, torch.cuda.synchronize)
 
+    # vvc355_recon_frame.workgroups: 0 (the pass's default, fastest for a picture alone) for the one-picture legs, fewer persistent workgroups
+    # while several pictures share the device (measured, eight in flight: 96 > 128 > 192 > 256 > 384 in frames/s; profiles/README.md)
+    def recon_workgroups(n):
+        for rf_ in RECON_FRAMES:
+            rf_.workgroups = n
+    concurrent_wgs = 96 if (gop or n_ff > 1) else 0
+    recon_workgroups(concurrent_wgs)
     for _ in range(args.warmup):
         run_step()
     barrier()
+    recon_workgroups(0)
     # Untimed pass of ONE frame alone with HIP events around every stage: the per-stage breakdown (`stages`), the latency of a frame
     # and which stage dominates.  The timed region then carries events around that one stage only.
     events = {}
@@ -1883,6 +1893,7 @@ def main(argv=None):
     # beside the other frames' kernels, so the kernel that bounds throughput is the largest of the batched stages
     throughput_stages = {k: v for k, v in breakdown.items() if k != "intra_recon_wavefront"} or breakdown
     dom_name = max(throughput_stages, key=throughput_stages.get)
+    recon_workgroups(concurrent_wgs)
     barrier()
     # secondary figure: F mutually independent frames per step (in GOP mode: the odd pictures of one group) — the ceiling without
     # reference dependencies
@@ -2028,7 +2039,8 @@ def main(argv=None):
                             f"{'uniform-noise' if args.noise else 'picture-like'} content; HBM-resident; "
                             f"stages per picture: {', '.join(st.name for st in chain)}",
                 "not_yet_in_chain": MISSING + ([] if MC_TOOLS == 3 and not args.only and AFFINE_FRAC == 0.06 and INTER_FRAC == 0.8 and SAO_TABLES and ALF_TABLES and not DEBLOCK_JOBS and not args.graph and not args.noise else ["PROFILING RUN: --noise / --graph / --mc-tools / --only / --affine-frac / --inter-frac / --sao-jobs / --alf-jobs / --deblock-jobs change the workload; not the metric"]),
-                "parallelism": f"{world} independent stream(s), one per GPU, no collective; {par}, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
+                "parallelism": f"{world} independent stream(s), one per GPU, no collective; {par}, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}; in-order pass: "
+                               f"{concurrent_wgs or 192} persistent workgroups per picture in the timed region, 192 for the one-picture legs (`stages`, frame_latency_ms)",
                 "frame_objects_built": len(objs) if gop else n_ff, "build_s": round(build_s, 1),
             },
             "roofline": {

@@ -278,7 +278,7 @@ class ReconFrame(ctypes.Structure):
         ("stride", ctypes.c_int32 * 3), ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("ctb_width", ctypes.c_int32),
         ("ctb_height", ctypes.c_int32), ("n_work", ctypes.c_int32),
         ("ctb_log2", ctypes.c_uint8), ("hs", ctypes.c_uint8), ("vs", ctypes.c_uint8), ("wpp", ctypes.c_uint8), ("collocated", ctypes.c_uint8),
-        ("pad_", ctypes.c_uint8 * 3), ("lmcs_model", ctypes.c_uint64),
+        ("pad_", ctypes.c_uint8), ("workgroups", ctypes.c_uint16), ("lmcs_model", ctypes.c_uint64),
     ]
 
 

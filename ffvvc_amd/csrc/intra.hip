@@ -1190,6 +1190,18 @@ __global__ __launch_bounds__(256) void lmcs_scale_kernel(const vvc355_lmcs_scale
 
 // lmcs_derive_chroma_scale (vvc_intra_template.c:390-429) of the 64x64 unit at (x, y) from a luma plane in HBM, one wave: lanes
 // 0 .. size - 1 fetch one left and one upper neighbour each (lmcs_sum_samples' replication beyond the picture = a clamped index)
+// The bin of lmcs_derive_chroma_scale's search (vvc_intra_template.c:421-426: from min_bin_idx up while avg >= pivot[bin + 1], at most to
+// max_bin_idx + 1) without its chain of dependent loads: lane l compares against pivot[l + 1], the first lane at or after min_bin_idx that
+// would stop the loop is the bin.  Then chroma_scale_coeff[min(bin, 15)].  Wave-uniform arguments and result.
+__device__ __forceinline__ int lmcs_scale_of_avg(const vvc355_lmcs_model *model, int avg, int lane)
+{
+    const int first = gld<uint8_t>(&model->min_bin_idx), last = gld<uint8_t>(&model->max_bin_idx);
+    const int pv = lane < 16 ? (int)gld<uint16_t>(&model->pivot[lane + 1]) : 0;
+    const bool stop = lane >= first && (lane > last || avg < pv);          // lane 16 stops at the latest (last <= 15)
+    const int bin = __builtin_ctzll(__builtin_amdgcn_ballot_w64(stop));
+    return __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&model->chroma_scale_coeff[min(bin, 15)]));
+}
+
 template <int BD>
 __device__ __forceinline__ int lmcs_scale_from_plane(const vvc355_lmcs_model *model, const uint8_t *luma, int ls, int x, int y, int size, bool avail_l, bool avail_t,
                                                      int pic_w, int pic_h, int lane)
@@ -1206,11 +1218,7 @@ __device__ __forceinline__ int lmcs_scale_from_plane(const vvc355_lmcs_model *mo
         v += __shfl_xor(v, sft, 64);
     const int cnt = (avail_l ? size : 0) + (avail_t ? size : 0);
     const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
-    int bin = gld<uint8_t>(&model->min_bin_idx);
-    const int last = gld<uint8_t>(&model->max_bin_idx);
-    while (bin <= last && avg >= (int)gld<uint16_t>(&model->pivot[bin + 1]))
-        bin++;
-    return __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&model->chroma_scale_coeff[min(bin, 15)]));
+    return lmcs_scale_of_avg(model, avg, lane);
 }
 
 // the tail of itransform for one block in HBM, one wave: joint sign / shift (pred_residual_joint), lmcs_scale_chroma when joint bit 3 is
@@ -1402,6 +1410,7 @@ struct ReconLds {
     int prm[2][8];
     uint32_t rmap[2][2][32];          // reconstructed areas of this CTU per channel type as bitmaps of 4x4-luma-sample units: [0] bit b of
                                       // word u = unit (b, u), [1] its transpose (see recon_top_available)
+    uint32_t cmdbuf[2][64 * 10];      // per wave: the window of 64 commands it is walking
     int luma_done;                    // commands the luma wave has passed (the chroma wave waits on it before CCLM)
     int bc[8];
     IntraTabsLds tabs;                // the predictors' constant tables (filled while the CTU waits for its neighbours)
@@ -1792,43 +1801,49 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
     const int ctb_mask = ctb - 1;
     constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
-    // Each wave walks only its own commands.  Windows of 64 commands: lane i fetches dword 6 (mode, kind, c_idx, ref_idx) of command
-    // win + i, a ballot gives the wave's commands in the window, the next window's dwords are already on their way.  The commands
-    // themselves (ten dwords, lane i holds dword i) are fetched two ahead through the vector-memory path (its counter is not shared
-    // with LDS traffic, so the fetches really overlap the blocks): the next command's contents are at hand when the current one
-    // starts — its residual can be requested early, a Cb / Cr twin recognised.
+    // Each wave walks only its own commands.  The list is taken in windows of 64 commands: the whole window (64 x 10 dwords, contiguous) goes
+    // from HBM into the wave's LDS buffer in one round trip, a ballot over the kinds (dword 6: mode, kind, c_idx, ref_idx) gives the wave's
+    // commands in the window, and every command is then an LDS read away — the global round trip is paid once per window, not per command
+    // (a register pipeline of per-command global loads makes every rotation wait for the load issued last).
+    static_assert(CMD_DW == 10, "cmdbuf holds windows of 10-dword commands");
     const uint32_t n_cmd = ctu.n_cmd;
     uint16_t (*arr)[kEdgeLen] = L.arr[role];
     const LTabs tabs{ &L.tabs };
-    auto load_kinds = [&](uint32_t base) -> uint32_t { return gld<uint32_t>((const uint32_t *)(cmds + min(base + (uint32_t)tid, n_cmd - 1)) + 6); };
-    auto own_mask = [&](uint32_t kinds, uint32_t base) -> unsigned long long {
+    VVC355_LDS uint32_t *cbuf = (VVC355_LDS uint32_t *)L.cmdbuf[role];
+    auto load_window = [&](uint32_t base) -> unsigned long long {
+        const uint32_t n_dw = min(64u, n_cmd - base) * CMD_DW;
+        const uint32_t *g = (const uint32_t *)(cmds + base);
+        uint32_t v[CMD_DW];
+#pragma unroll
+        for (int u = 0; u < CMD_DW; u++)
+            v[u] = (uint32_t)tid + 64u * u < n_dw ? gld<uint32_t>(g + tid + 64 * u) : 0u;
+#pragma unroll
+        for (int u = 0; u < CMD_DW; u++)
+            cbuf[tid + 64 * u] = v[u];
+        group_sync<64>();
+        const uint32_t kinds = cbuf[tid * CMD_DW + 6];
         return __ballot(base + (uint32_t)tid < n_cmd && ((((kinds >> 16) & 0xff) > 0) == (role == 1)));
     };
-    auto load_cmd = [&](int idx) -> uint32_t { return idx >= 0 ? gld<uint32_t>((const uint32_t *)(cmds + idx) + min(tid, CMD_DW - 1)) : 0u; };
     uint32_t win = 0;
-    unsigned long long mask = own_mask(load_kinds(0), 0);
-    uint32_t kinds_nx = load_kinds(64);
+    unsigned long long mask = load_window(0);
     auto advance = [&]() -> int {         // index of the wave's next command, -1 when its list is exhausted
         while (!mask) {
             if (win + 64 >= n_cmd)
                 return -1;
             win += 64;
-            mask = own_mask(kinds_nx, win);
-            kinds_nx = load_kinds(win + 64);
+            mask = load_window(win);
         }
         const int bit = __builtin_ctzll(mask);
         mask &= mask - 1;
         return (int)win + bit;
     };
-    int i0 = advance(), i1 = i0 >= 0 ? advance() : -1, i2 = i1 >= 0 ? advance() : -1;
-    uint32_t d0 = load_cmd(i0), d1 = load_cmd(i1), d2 = load_cmd(i2);
+    auto load_cmd = [&](int idx) -> uint32_t { return cbuf[(idx - (int)win) * CMD_DW + min(tid, CMD_DW - 1)]; };      // lane i holds dword i
+    int i0 = advance();
     // luma_done = every luma command below this index is finished (the chroma wave waits on it before CCLM)
     if (role == 0)
         recon_luma_done_set(L, i0 >= 0 ? i0 : (int)n_cmd);
     auto shift = [&]() {
-        i0 = i1; d0 = d1; i1 = i2; d1 = d2;
-        i2 = i1 >= 0 ? advance() : -1;
-        d2 = load_cmd(i2);
+        i0 = advance();
         if (role == 0)
             recon_luma_done_set(L, i0 >= 0 ? i0 : (int)n_cmd);          // issued after the finished command's stores (LDS: in order; planes: after s_waitcnt vmcnt(0))
     };
@@ -1837,6 +1852,8 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     int lmcs_xv = -1, lmcs_yv = -1, lmcs_scale = 0;      // lc->lmcs: the 64x64 unit whose chroma residual scale is known (reset per CTU, vvc_intra.c:509-510)
     while (i0 >= 0) {
         const uint32_t k = (uint32_t)i0;
+        const int i1 = mask ? (int)win + __builtin_ctzll(mask) : -1;        // the wave's next command, when this window holds it
+        const uint32_t d0 = load_cmd(i0), d1 = i1 >= 0 ? load_cmd(i1) : 0u;
         vvc355_recon_cmd c;
         bool pair_next = false;
         {
@@ -1984,12 +2001,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                     v += __shfl_xor(v, sft, 64);
                 const int cnt = (avail_l ? size_y : 0) + (avail_t ? size_y : 0);
                 const int avg = cnt ? (v + (cnt >> 1)) >> ilog2i(cnt) : 1 << (BD - 1);
-                const vvc355_lmcs_model *lm = (const vvc355_lmcs_model *)f.lmcs_model;
-                int bin = gld<uint8_t>(&lm->min_bin_idx);
-                const int last = gld<uint8_t>(&lm->max_bin_idx);
-                while (bin <= last && avg >= (int)gld<uint16_t>(&lm->pivot[bin + 1]))
-                    bin++;
-                lmcs_scale = __builtin_amdgcn_readfirstlane((int)gld<uint16_t>(&lm->chroma_scale_coeff[min(bin, 15)]));
+                lmcs_scale = lmcs_scale_of_avg((const vvc355_lmcs_model *)f.lmcs_model, avg, tid);
             }
             auto resid_of = [&](int r) {                        // the joint sign / shift (pred_residual_joint), then lmcs_scale_chroma
                 if (c.joint & 1)
@@ -2175,7 +2187,7 @@ void vvc355_recon_frame_pass(void *stream, int bd, const vvc355_recon_frame *fra
     // enough workgroups for the CTUs that can run at once (independent intra clusters of an inter picture; half a CTU row of an intra
     // picture), few enough that their LDS leaves room for the other frames' kernels.  VVC355_RECON_GRID overrides (tuning aid).
     static const int grid_env = [] { const char *e = getenv("VVC355_RECON_GRID"); return e ? atoi(e) : 0; }();
-    const int grid = std::min(frame_host->n_work, grid_env > 0 ? grid_env : 256);
+    const int grid = std::min(frame_host->n_work, grid_env > 0 ? grid_env : frame_host->workgroups ? (int)frame_host->workgroups : 192);
     if (tile)
         VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((recon_wavefront_kernel<BD, true>), dim3(grid), dim3(128), 0, (hipStream_t)stream, frame_dev));
     else

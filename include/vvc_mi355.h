@@ -948,7 +948,9 @@ typedef struct vvc355_recon_frame {
     uint8_t  ctb_log2, hs, vs;
     uint8_t  wpp;                 /* sps_entropy_coding_sync_enabled_flag */
     uint8_t  collocated;          /* sps_chroma_vertical_collocated_flag */
-    uint8_t  pad_[3];
+    uint8_t  pad_;
+    uint16_t workgroups;          /* persistent workgroups of the pass (each holds 77 KB of LDS while it walks or waits); 0 = 192, the fastest for one
+                                   * picture alone — a host that keeps several pictures in flight does better with fewer (about 96 with eight) */
     uint64_t lmcs_model;          /* 0, or DEVICE vvc355_lmcs_model: the picture's LMCS model for RESID commands with joint bit 3 (chroma residual scaling) */
 } vvc355_recon_frame;
 size_t vvc355_recon_state_bytes(int n_ctus);

@@ -346,7 +346,8 @@ typedef struct orc_recon_frame {
     uint64_t slice_idx, ctb_to_col_bd, ctb_to_row_bd;
     int32_t  stride[3];
     int32_t  width, height, ctb_width, ctb_height, n_work;
-    uint8_t  ctb_log2, hs, vs, wpp, collocated, pad_[3];
+    uint8_t  ctb_log2, hs, vs, wpp, collocated, pad_;
+    uint16_t workgroups;          /* scheduling hint of the device pass; unused here */
     uint64_t lmcs_model;          /* 0, or orc_lmcs_model for RESID commands with joint bit 3 */
 } orc_recon_frame;
 typedef struct orc_lmcs_model {
