@@ -1699,6 +1699,10 @@ def parse_args(argv=None):
     ap.add_argument("--with-upload", action="store_true", help="--gop 0: additionally time the steps with every per-frame descriptor copied from pinned host memory first "
                                                                "(GOP mode always reports it: incl_descriptor_upload)")
     ap.add_argument("--no-upload", action="store_true", help="GOP mode: skip the incl_descriptor_upload leg")
+    ap.add_argument("--gop-check", type=int, default=0, metavar="GROUPS",
+                    help="GOP mode, no timing: decode GROUPS groups with the concurrent scheduler (one stream per picture, event waits on the reference pictures), "
+                         "again one picture at a time in decoding order on one stream, and once more serially in REVERSED order; prints how many decoded pictures "
+                         "differ between the first two (must be 0) and between the last two (must not be 0: the pictures really read their references)")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed oracle check of one step (the `verified` object)")
     ap.add_argument("--verify-ctus", type=int, default=32, help="CTUs sampled for the prediction / transform stages of the oracle check")
     ap.add_argument("--no-lmcs", action="store_true", help="profiling aid: a picture without LMCS (no forward map on the inter prediction, no chroma residual scaling)")
@@ -1876,6 +1880,44 @@ def main(argv=None):
             rf_.workgroups = n
     concurrent_wgs = 96 if (gop or n_ff > 1) else 0
     recon_workgroups(concurrent_wgs)
+    if args.gop_check:
+        if not gop:
+            raise SystemExit("--gop-check needs --gop")
+        keys = sorted(objs)
+        state = [t for key in keys for t in objs[key].out]            # the decoded pictures: what later pictures predict from
+        init = [t.clone() for t in state]
+
+        def restart():
+            torch.cuda.synchronize()
+            for t, t0 in zip(state, init):
+                t.copy_(t0)
+            recorded.clear()
+            torch.cuda.synchronize()
+
+        def serial(pictures):
+            restart()
+            for k in range(args.gop_check):
+                for (poc, _lo, _hi) in pictures:
+                    for st in chains_of[(k % n_sets, poc)]:
+                        st.launch(streams[0].cuda_stream)
+                    torch.cuda.synchronize()
+            return [t.clone() for t in state]
+
+        restart()
+        for k in range(args.gop_check):
+            run_gop(k)
+        torch.cuda.synchronize()
+        concurrent = [t.clone() for t in state]
+        in_order, reversed_order = serial(order), serial(order[::-1])
+        n_pic = len(keys)
+        per_pic = lambda a, b: sum(any(not torch.equal(a[3 * i + c], b[3 * i + c]) for c in range(3)) for i in range(n_pic))      # noqa: E731
+        rep = {"gop_check": {"groups": args.gop_check, "pictures": n_pic, "gop": gop, "streams": len(streams),
+                             "concurrent_vs_in_order_mismatching_pictures": per_pic(concurrent, in_order),
+                             "in_order_vs_reversed_order_differing_pictures": per_pic(in_order, reversed_order),
+                             "pictures_changed_by_decoding": per_pic(in_order, init)}}
+        print(json.dumps(rep))
+        ok = rep["gop_check"]["concurrent_vs_in_order_mismatching_pictures"] == 0 and rep["gop_check"]["in_order_vs_reversed_order_differing_pictures"] > 0
+        raise SystemExit(0 if ok else 1)
     for _ in range(args.warmup):
         run_step()
     barrier()

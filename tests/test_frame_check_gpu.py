@@ -32,3 +32,17 @@ def test_bench_frame_against_oracle(width, height, bd, noise):
         st = rep["stats"]
         assert 0.05 < st["dmvr_searched_fraction"] <= 1.0 and 0.02 < st["bdof_applied_fraction"] < 0.98, st
         assert st["deblock_vertical_changed_luma_sample_fraction"] > 0.01, st
+
+
+@pytest.mark.parametrize("gop,groups", [(4, 3), (8, 2)])
+def test_gop_stream_matches_serial_decoding(gop, groups):
+    """bench.py --gop: every picture on its own stream, waiting for its two reference pictures through events (three rotating picture
+    sets, so a group's first pictures start while the previous group drains).  The decoded pictures must be those of decoding one
+    picture at a time in decoding order — and decoding in the wrong order must give different pictures, or the check would say nothing
+    about the waits."""
+    r = subprocess.run([sys.executable, "bench.py", "--gop", str(gop), "--gop-check", str(groups), "--width", "832", "--height", "480", "--no-cpu-baseline", "--no-upload"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith('{"gop_check"')))["gop_check"]
+    assert rep["concurrent_vs_in_order_mismatching_pictures"] == 0, rep
+    assert rep["in_order_vs_reversed_order_differing_pictures"] > 0 and rep["pictures_changed_by_decoding"] == gop * min(groups, 3), rep
