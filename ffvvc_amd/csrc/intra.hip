@@ -1408,8 +1408,8 @@ struct ReconLds {
     uint16_t arr[3][4][kEdgeLen];     // edge arrays and scratch: luma wave, chroma wave (third set: Cr when Cb and Cr are predicted together)
     int scratch[3][16];
     int prm[2][8];
-    uint32_t rmap[2][2][32];          // reconstructed areas of this CTU per channel type as bitmaps of 4x4-luma-sample units: [0] bit b of
-                                      // word u = unit (b, u), [1] its transpose (see recon_top_available)
+    uint32_t rmap[2][2][2][32];       // per wave (the availability pre-pass of recon_one_ctu): reconstructed areas of this CTU per channel type as
+                                      // bitmaps of 4x4-luma-sample units: [0] bit b of word u = unit (b, u), [1] its transpose (see recon_top_available)
     uint32_t cmdbuf[2][64 * 10];      // per wave: the window of 64 commands it is walking
     int luma_done;                    // commands the luma wave has passed (the chroma wave waits on it before CCLM)
     int bc[8];
@@ -1430,7 +1430,8 @@ __device__ __forceinline__ int recon_run(uint32_t line, int from)
     return m == ~0u ? 32 : __builtin_ctz(~m);
 }
 // ff_vvc_get_top_available (vvc_intra.c:591-620), one wave (uniform arguments, uniform result)
-__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_x0, int x, int y, int target, int c_idx)
+typedef uint32_t ReconMaps[2][2][32];
+__device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconMaps &rmap, int cu_x0, int x, int y, int target, int c_idx)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int end_of_ctb_x = ((cu_x0 >> f.ctb_log2) + 1) << f.ctb_log2;
@@ -1446,11 +1447,11 @@ __device__ int recon_top_available(const vvc355_recon_frame &f, const ReconCtx &
     }
     target = max(0, min(target, max_x - x));
     const int ux = ((x << hs) - cx.ox) >> 2, uy = (((y - 1) << vs) - cx.oy) >> 2;
-    const int end = (cx.ox + ((ux + recon_run(L.rmap[c_idx > 0][0][uy], ux)) << 2)) >> hs;
+    const int end = (cx.ox + ((ux + recon_run(rmap[c_idx > 0][0][uy], ux)) << 2)) >> hs;
     return max(0, min(target, end - x));
 }
 // ff_vvc_get_left_available (vvc_intra.c:622-648), one wave
-__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconLds &L, int cu_y0, int x, int y, int target, int c_idx)
+__device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx &cx, const ReconMaps &rmap, int cu_y0, int x, int y, int target, int c_idx)
 {
     const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
     const int x0b = x & ((1 << (f.ctb_log2 - hs)) - 1);
@@ -1462,7 +1463,7 @@ __device__ int recon_left_available(const vvc355_recon_frame &f, const ReconCtx 
     if (!x0b)
         return target;
     const int ux = (((x - 1) << hs) - cx.ox) >> 2, uy = ((y << vs) - cx.oy) >> 2;
-    const int end = (cx.oy + ((uy + recon_run(L.rmap[c_idx > 0][1][ux], uy)) << 2)) >> vs;
+    const int end = (cx.oy + ((uy + recon_run(rmap[c_idx > 0][1][ux], uy)) << 2)) >> vs;
     return max(0, min(target, end - y));
 }
 // ff_vvc_wide_angle_mode_mapping (vvc_intra.c:693-714)
@@ -1696,7 +1697,6 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         L.bc[0] = __builtin_amdgcn_readfirstlane(t);
         recon_luma_done_set(L, 0);
     }
-    ((uint32_t *)L.rmap[role])[tid] = 0;             // this wave's channel type starts with nothing reconstructed (both waves are past the previous CTU's last barrier)
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(L.bc[0]);
     if (ticket >= f.n_work)
@@ -1751,6 +1751,98 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         }
         ps0 = kBodyLumaP; ps1 = kBodyChromaP;
     }
+    const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
+    const int ctb_mask = ctb - 1;
+    constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
+    // Each wave walks only its own commands, and no MARKs (see the availability pre-pass below).  The list is taken in windows of 64 commands: the whole window (64 x 10 dwords, contiguous) goes
+    // from HBM into the wave's LDS buffer in one round trip, a ballot over the kinds (dword 6: mode, kind, c_idx, ref_idx) gives the wave's
+    // commands in the window, and every command is then an LDS read away — the global round trip is paid once per window, not per command
+    // (a register pipeline of per-command global loads makes every rotation wait for the load issued last).
+    static_assert(CMD_DW == 10, "cmdbuf holds windows of 10-dword commands");
+    const uint32_t n_cmd = ctu.n_cmd;
+    uint16_t (*arr)[kEdgeLen] = L.arr[role];
+    const LTabs tabs{ &L.tabs };
+    VVC355_LDS uint32_t *cbuf = (VVC355_LDS uint32_t *)L.cmdbuf[role];
+    auto load_window = [&](uint32_t base, uint32_t *all_kinds) -> unsigned long long {
+        const uint32_t n_dw = min(64u, n_cmd - base) * CMD_DW;
+        const uint32_t *g = (const uint32_t *)(cmds + base);
+        uint32_t v[CMD_DW];
+#pragma unroll
+        for (int u = 0; u < CMD_DW; u++)
+            v[u] = (uint32_t)tid + 64u * u < n_dw ? gld<uint32_t>(g + tid + 64 * u) : 0u;
+#pragma unroll
+        for (int u = 0; u < CMD_DW; u++)
+            cbuf[tid + 64 * u] = v[u];
+        group_sync<64>();
+        const uint32_t kinds = cbuf[tid * CMD_DW + 6];
+        *all_kinds = kinds;
+        return __ballot(base + (uint32_t)tid < n_cmd && ((((kinds >> 16) & 0xff) > 0) == (role == 1)) && ((kinds >> 8) & 0xff) != VVC355_RECON_MARK);
+    };
+    // Availability pre-pass.  What ff_vvc_get_top_available / _left_available return for a block depends on the command list alone (the areas
+    // the MARKs before it record), not on any sample — so it does not belong on the chain of dependent blocks.  Before waiting for the
+    // neighbours each wave runs through the whole list once: MARKs update its bitmaps of reconstructed 4x4 units (the chroma wave keeps the
+    // luma bitmap as well: CCLM and the chroma residual scale ask about luma neighbours), and for each of its own PRED / CCLM / scaled RESID
+    // commands the answers go into the command's pad bytes in HBM (dword 9 = left | top << 16 in the component's samples; pad_[0] bits
+    // 0 / 1 = the 1-sample luma questions).  The walk below reads them back with the command and never sees a MARK.  A workgroup that
+    // took its ticket ahead of its neighbours — the usual case on a dependency chain — does this while it would be waiting anyway.
+    {
+        ReconMaps &rmap = L.rmap[role];
+        ((uint32_t *)rmap)[tid] = 0;
+        ((uint32_t *)rmap)[tid + 64] = 0;
+        uint32_t *cmd_dw = (uint32_t *)cmds;
+        for (uint32_t base = 0; base < n_cmd; base += 64) {
+            uint32_t kinds;
+            (void)load_window(base, &kinds);
+            const uint32_t kind_l = (kinds >> 8) & 0xff, type_l = ((kinds >> 16) & 0xff) > 0;
+            const bool in_l = base + (uint32_t)tid < n_cmd;
+            const bool mine = type_l == (uint32_t)role;
+            // MARKs of the types this wave tracks; its own PREDs and CCLMs; its own RESIDs with chroma residual scaling (joint bit 3: dword 8, byte 1)
+            const bool scaled_l = in_l && mine && kind_l == VVC355_RECON_RESID && ((cbuf[tid * CMD_DW + 8] >> 8) & 8);
+            unsigned long long todo = __ballot(in_l && ((kind_l == VVC355_RECON_MARK && (role == 1 || type_l == 0)) ||
+                                                        (mine && (kind_l == VVC355_RECON_PRED || kind_l == VVC355_RECON_CCLM)) || scaled_l));
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t q2 = __builtin_amdgcn_readfirstlane(cbuf[k * CMD_DW + 2]), q3 = __builtin_amdgcn_readfirstlane(cbuf[k * CMD_DW + 3]);
+                const uint32_t q4 = __builtin_amdgcn_readfirstlane(cbuf[k * CMD_DW + 4]), q6 = __builtin_amdgcn_readfirstlane(cbuf[k * CMD_DW + 6]);
+                const int x0 = (int16_t)(q2 & 0xffff), y0 = (int16_t)(q2 >> 16), cw_ = (int16_t)(q3 & 0xffff), ch_ = (int16_t)(q3 >> 16);
+                const int cu_x0 = (int16_t)(q4 & 0xffff), cu_y0 = (int16_t)(q4 >> 16);
+                const int kind = (q6 >> 8) & 0xff, c_idx = (q6 >> 16) & 0xff;
+                if (kind == VVC355_RECON_MARK) {
+                    // add_reconstructed_area (vvc_intra.c:188-206): lanes 0-31 set the unit rows, lanes 32-63 the unit columns
+                    const int ux = (x0 - cx.ox) >> 2, uy = (y0 - cx.oy) >> 2, uw = max(1, cw_ >> 2), uh = max(1, ch_ >> 2);
+                    const int i = tid & 31, t = tid >> 5;
+                    const int span = t ? uw : uh, first = t ? ux : uy, len = t ? uh : uw, at = t ? uy : ux;
+                    if (i < span)
+                        rmap[c_idx > 0][t][first + i] |= (len >= 32 ? ~0u : ((1u << len) - 1)) << at;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // LDS accesses of a wave stay in order; this only pins the compiler
+                    continue;
+                }
+                uint32_t dw9 = 0, bits = 0;
+                if (kind == VVC355_RECON_PRED) {
+                    const int hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+                    dw9 = (uint32_t)(uint16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, rmap, cu_y0, x0 >> hs, y0 >> vs, 16384, c_idx)) |
+                          (uint32_t)(uint16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, rmap, cu_x0, x0 >> hs, y0 >> vs, 16384, c_idx)) << 16;
+                } else if (kind == VVC355_RECON_CCLM) {
+                    dw9 = (uint32_t)(uint16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, rmap, cu_y0, x0 >> f.hs, y0 >> f.vs, 16384, 1)) |
+                          (uint32_t)(uint16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, rmap, cu_x0, x0 >> f.hs, y0 >> f.vs, 16384, 1)) << 16;
+                    bits = (__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, rmap, cu_y0, x0, y0, 1, 0)) != 0 ? 1u : 0u) |
+                           (__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, rmap, cu_x0, x0, y0, 1, 0)) != 0 ? 2u : 0u);
+                } else {
+                    // the 64x64 unit of the coding unit (lmcs_derive_chroma_scale, vvc_intra_template.c:399-404)
+                    const int size_y = min(ctb, 64), xv = cu_x0 & ~(size_y - 1), yv = cu_y0 & ~(size_y - 1);
+                    bits = (__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, rmap, cu_y0, xv, yv, 1, 0)) != 0 ? 1u : 0u) |
+                           (__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, rmap, cu_x0, xv, yv, 1, 0)) != 0 ? 2u : 0u);
+                }
+                if (tid == 0) {
+                    uint32_t *g = cmd_dw + (size_t)(base + k) * CMD_DW;
+                    gst<uint32_t>(g + 9, dw9);
+                    gst<uint8_t>((uint8_t *)(g + 8) + 2, (uint8_t)bits);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the answers are in L2 before this wave fetches its windows again (after the acquire below)
+    }
     // Wait for the neighbours this wave reads — left, upper-left, upper, upper-right, those that have commands.  The luma wave needs their
     // LUMA only (flag raised as soon as a neighbour's luma commands are done; a LIGHT neighbour's luma was final before the pass), the
     // chroma wave the whole neighbour.  From here to the join at the end the two waves run on their own: each waits, loads its own edges
@@ -1798,40 +1890,14 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
 #ifdef VVC355_RECON_PROF
     const long long c_loop = clock64();
 #endif
-    const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
-    const int ctb_mask = ctb - 1;
-    constexpr int CMD_DW = (int)sizeof(vvc355_recon_cmd) / 4;
-    // Each wave walks only its own commands.  The list is taken in windows of 64 commands: the whole window (64 x 10 dwords, contiguous) goes
-    // from HBM into the wave's LDS buffer in one round trip, a ballot over the kinds (dword 6: mode, kind, c_idx, ref_idx) gives the wave's
-    // commands in the window, and every command is then an LDS read away — the global round trip is paid once per window, not per command
-    // (a register pipeline of per-command global loads makes every rotation wait for the load issued last).
-    static_assert(CMD_DW == 10, "cmdbuf holds windows of 10-dword commands");
-    const uint32_t n_cmd = ctu.n_cmd;
-    uint16_t (*arr)[kEdgeLen] = L.arr[role];
-    const LTabs tabs{ &L.tabs };
-    VVC355_LDS uint32_t *cbuf = (VVC355_LDS uint32_t *)L.cmdbuf[role];
-    auto load_window = [&](uint32_t base) -> unsigned long long {
-        const uint32_t n_dw = min(64u, n_cmd - base) * CMD_DW;
-        const uint32_t *g = (const uint32_t *)(cmds + base);
-        uint32_t v[CMD_DW];
-#pragma unroll
-        for (int u = 0; u < CMD_DW; u++)
-            v[u] = (uint32_t)tid + 64u * u < n_dw ? gld<uint32_t>(g + tid + 64 * u) : 0u;
-#pragma unroll
-        for (int u = 0; u < CMD_DW; u++)
-            cbuf[tid + 64 * u] = v[u];
-        group_sync<64>();
-        const uint32_t kinds = cbuf[tid * CMD_DW + 6];
-        return __ballot(base + (uint32_t)tid < n_cmd && ((((kinds >> 16) & 0xff) > 0) == (role == 1)));
-    };
-    uint32_t win = 0;
-    unsigned long long mask = load_window(0);
+    uint32_t win = 0, kinds_unused;
+    unsigned long long mask = load_window(0, &kinds_unused);
     auto advance = [&]() -> int {         // index of the wave's next command, -1 when its list is exhausted
         while (!mask) {
             if (win + 64 >= n_cmd)
                 return -1;
             win += 64;
-            mask = load_window(win);
+            mask = load_window(win, &kinds_unused);
         }
         const int bit = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -1856,11 +1922,13 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
         const uint32_t d0 = load_cmd(i0), d1 = i1 >= 0 ? load_cmd(i1) : 0u;
         vvc355_recon_cmd c;
         bool pair_next = false;
+        uint32_t avail_dw;                   // dword 9: the pre-pass's answers (left | top << 16)
         {
             uint32_t w[CMD_DW];
 #pragma unroll
             for (int i = 0; i < CMD_DW; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)d0, i);
             __builtin_memcpy(&c, w, sizeof(c));
+            avail_dw = w[9];
             if (i1 >= 0) {
                 const uint32_t n6 = (uint32_t)__builtin_amdgcn_readlane((int)d1, 6);
                 // the wave's next command is a residual block: start its first loads now, so that they travel while this command
@@ -1888,23 +1956,15 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             }
         }
         const unsigned long long t_cmd = RPROF_NOW();
-        if (c.kind == VVC355_RECON_MARK) {
-            // add_reconstructed_area (vvc_intra.c:188-206): lanes 0-31 set the unit rows, lanes 32-63 the unit columns
-            const int ux = (c.x0 - cx.ox) >> 2, uy = (c.y0 - cx.oy) >> 2, uw = max(1, c.w >> 2), uh = max(1, c.h >> 2);
-            const int i = tid & 31, t = tid >> 5;
-            const int span = t ? uw : uh, first = t ? ux : uy, len = t ? uh : uw, at = t ? uy : ux;
-            if (i < span)
-                L.rmap[role][t][first + i] |= (len >= 32 ? ~0u : ((1u << len) - 1)) << at;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // LDS accesses of a wave stay in order; this only pins the compiler
-        } else if (c.kind == VVC355_RECON_PRED) {
+        if (c.kind == VVC355_RECON_PRED) {
             const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
             const int x = c.x0 >> hs, y = c.y0 >> vs, w = c.w >> hs, h = c.h >> vs;
             vvc355_intra_job j = {};
             j.x = (int16_t)x; j.y = (int16_t)y; j.w = (int16_t)w; j.h = (int16_t)h;
             j.mode = (int16_t)wide_angle_mode(c.isp_split, c_idx, w, h, c.cb_width, c.cb_height, c.mode);
             j.cb_width = c.cb_width; j.cb_height = c.cb_height;
-            j.left_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, x, y, 16384, c_idx));
-            j.top_avail = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, x, y, 16384, c_idx));
+            j.left_avail = (int16_t)(avail_dw & 0xffff);
+            j.top_avail = (int16_t)(avail_dw >> 16);
             j.c_idx = (uint8_t)c_idx; j.ref_idx = c_idx ? 0 : c.ref_idx;
             j.is_mip = c.is_mip; j.mip_mode = c.mip_mode; j.mip_transposed = c.mip_transposed;
             j.isp_split = c.isp_split; j.bdpcm_flag = c.bdpcm_flag;
@@ -1941,11 +2001,11 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
             group_sync<64>();
             vvc355_cclm_job j = {};
             j.x0 = c.x0; j.y0 = c.y0; j.width = c.w; j.height = c.h;
-            j.top_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1));
-            j.left_avail_c = (int16_t)__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, c.x0 >> f.hs, c.y0 >> f.vs, 16384, 1));
+            j.top_avail_c = (int16_t)(avail_dw >> 16);
+            j.left_avail_c = (int16_t)(avail_dw & 0xffff);
             j.mode = (uint8_t)c.mode; j.hs = f.hs; j.vs = f.vs;
-            j.avail_t = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, c.x0, c.y0, 1, 0)) != 0);
-            j.avail_l = (uint8_t)(__builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, c.x0, c.y0, 1, 0)) != 0);
+            j.avail_t = (uint8_t)((c.pad_[0] >> 1) & 1);
+            j.avail_l = (uint8_t)(c.pad_[0] & 1);
             j.collocated = f.collocated;
             j.ctu_boundary = (c.y0 & ctb_mask) == 0;
             StripRef s0 = st0, s1 = st1, s2 = st2;
@@ -1983,8 +2043,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
                 group_sync<64>();
                 const int size_y = min(ctb, 64);
                 lmcs_xv = c.cu_x0 & ~(size_y - 1); lmcs_yv = c.cu_y0 & ~(size_y - 1);
-                const bool avail_t = __builtin_amdgcn_readfirstlane(recon_top_available(f, cx, L, c.cu_x0, lmcs_xv, lmcs_yv, 1, 0)) != 0;
-                const bool avail_l = __builtin_amdgcn_readfirstlane(recon_left_available(f, cx, L, c.cu_y0, lmcs_xv, lmcs_yv, 1, 0)) != 0;
+                const bool avail_t = (c.pad_[0] >> 1) & 1, avail_l = c.pad_[0] & 1;
                 StripRef s0 = st0;
                 s0.on = TILE && (lmcs_yv & ctb_mask) == 0;
                 int v = 0;

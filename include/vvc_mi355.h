@@ -897,7 +897,8 @@ int  vvc355_derive_transform_type(int tu_flags, int mts_idx, int lfnst_idx, int 
  *   CIIP   inter.put_ciip after the PRED of a combined inter / intra coding unit (ff_vvc_predict_ciip, vvc_inter.c:915; luma
  *          coordinates): resid = the inter prediction of the batched stage (w x h pixels of the component, packed rows),
  *          joint = the intra weight ciip_derive_intra_weight (:530-548) gives
- * Neighbour availability is derived on the device the way ff_vvc_get_top_available / _left_available do (:574-648): the
+ * Neighbour availability is derived on the device the way ff_vvc_get_top_available / _left_available do (:574-648), in a pass over
+ * the CTU's list that runs before the CTU waits for its neighbours (the answers depend on the list alone, not on samples): the
  * areas the MARK commands record — for the current CTU only, as in the reference (:508) — are kept as a bitmap of 4x4-luma-sample
  * units, and the length of the covered run above / left of a block is what the reference's walk over its area list returns for the
  * areas a decoder produces (disjoint blocks of one partitioning in coding order, inside the CTU, positions and sizes multiples of
@@ -921,7 +922,8 @@ typedef struct vvc355_recon_cmd {
                                 * vvc_intra.c:180-182 — goes through lmcs_scale_chroma (vvc_intra_template.c:431) with the scale of the 64x64
                                 * unit of (cu_x0, cu_y0), derived from the reconstructed luma left of and above that unit (:390-429) and kept
                                 * for the rest of the CTU as lc->lmcs does (reset per CTU, vvc_intra.c:509-510); needs frame.lmcs_model */
-    uint8_t  pad_[6];
+    uint8_t  pad_[6];          /* written by the pass itself (the commands live in DEVICE memory, read-write): the availability answers of
+                                * its pre-pass — whatever the host puts here is overwritten */
 } vvc355_recon_cmd;
 /*
  * flags: what the host knows about a CTU's place in the dependency web (0 = an ordinary CTU: it waits for its left, upper-left, upper
