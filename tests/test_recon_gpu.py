@@ -43,6 +43,8 @@ def run_case(dev, orc, rng, bd, w, h, ctb_log2, fmt, ticket_order="raster", work
     d_planes = [batch.DeviceBuffer.from_host(p) for p in pitched]
     d_res, d_inter = batch.DeviceBuffer.from_host(resid), batch.DeviceBuffer.from_host(inter)
     dcmd = work.bind(d_res.ptr, d_inter.ptr, isz)
+    # the commands' pad bytes belong to the pass (its availability pre-pass writes them): whatever the host leaves there must not matter
+    dcmd.view(np.uint8).reshape(len(dcmd), -1)[:, 34:40] = np.random.default_rng(len(dcmd)).integers(0, 256, size=(len(dcmd), 6), dtype=np.uint8)
     d_cmds, d_ctus, d_order = batch.DeviceBuffer.from_host(dcmd.view(np.uint8)), batch.DeviceBuffer.from_host(work.ctus.view(np.uint8)), batch.DeviceBuffer.from_host(work.order if len(work.order) else np.zeros(1, np.int32))
     d_state = batch.DeviceBuffer(dev.vvc355_recon_state_bytes(work.ncx * work.ncy))
     d_slice, d_col, d_row = batch.DeviceBuffer.from_host(work.slice_idx), batch.DeviceBuffer.from_host(work.col_bd), batch.DeviceBuffer.from_host(work.row_bd)
