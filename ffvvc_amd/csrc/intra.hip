@@ -1223,7 +1223,7 @@ __device__ __forceinline__ int lmcs_scale_from_plane(const vvc355_lmcs_model *mo
 
 // the tail of itransform for one block in HBM, one wave: joint sign / shift (pred_residual_joint), lmcs_scale_chroma when joint bit 3 is
 // set, add_residual; four samples of a row per lane and step (one at a time for blocks narrower than four)
-template <int BD>
+template <int BD, int NL = 64>
 __device__ __forceinline__ void resid_block_add(uint8_t *dst, int dst_stride, const int *res, int w, int h, int joint, int scale, int lane)
 {
     auto resid_of = [&](int r) {
@@ -1237,13 +1237,13 @@ __device__ __forceinline__ void resid_block_add(uint8_t *dst, int dst_stride, co
     };
     const int n = w * h, lw = ilog2i(w);
     if (w < 4) {
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += NL) {
             uint8_t *row = dst + row_off(i >> lw, dst_stride);
             st_px<BD>(row, i & (w - 1), clip_px<BD>(ld_px<BD>(row, i & (w - 1)) + resid_of(gld<int>(res + i))));
         }
         return;
     }
-    for (int i = lane * 4; i < n; i += 256) {
+    for (int i = lane * 4; i < n; i += NL * 4) {
         const int4 r4 = gld<int4>(res + i);
         uint8_t *row = dst + row_off(i >> lw, dst_stride);
         const int xo = i & (w - 1);
@@ -1280,20 +1280,47 @@ __global__ __launch_bounds__(256) void lmcs_vpdu_scale_kernel(const vvc355_lmcs_
         gst<int16_t>((int16_t *)f.scale + u, (int16_t)s);
 }
 
-// One wave per chroma block: the 64x64 unit's scale from the luma plane, then the residual added to the block.
+// Sixteen lanes per chroma block, four blocks per wave (a typical block of an inter coding unit is 8x8: one step of four samples per lane;
+// a wave per block left three quarters of the lanes idle and the launch was bound by its wave count — one slot per transform block of the
+// picture, most of them empty).  The block's scale comes from the picture's table (joint bit 4); a job that wants it derived from the luma
+// plane (bit 3 alone) gets the whole wave for that, one such job after the other, before the groups add their blocks.
 template <int BD>
 __global__ __launch_bounds__(256) void lmcs_chroma_resid_kernel(const vvc355_lmcs_resid_job *__restrict__ jobs, int n_jobs, const vvc355_lmcs_model *__restrict__ model)
 {
     using px_t = typename Px<BD>::type;
-    const int ji = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (ji >= n_jobs)
+    const int lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;             // the wave's four slots
+    if (first >= n_jobs)
         return;
-    const vvc355_lmcs_resid_job j = load_uniform(jobs + ji);
+    const int ji = first + g;
+    vvc355_lmcs_resid_job j = {};
+    if (ji < n_jobs) {
+        // 56 bytes: three 16-byte pieces and one of 8 (the struct is 8-byte aligned; the lanes of a group read the same addresses)
+        const uint2 *p = (const uint2 *)(jobs + ji);
+        uint2 q[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) q[i] = gld<uint2>(p + i);
+        __builtin_memcpy(&j, q, sizeof(j));
+    }
+    int scale = 0;
+    const bool derive = j.w > 0 && (j.joint & 8) && !(j.joint & 16);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(derive && l16 == 0);
+    while (todo) {                                   // wave-uniform: the group's parameters through its first lane
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        auto u32 = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+        const uint64_t luma = (uint64_t)u32((uint32_t)j.luma) | ((uint64_t)u32((uint32_t)(j.luma >> 32)) << 32);
+        const int s_ = lmcs_scale_from_plane<BD>(model, (const uint8_t *)luma, (int)u32((uint32_t)j.luma_stride) / (int)sizeof(px_t), (int16_t)u32((uint16_t)j.x_vpdu),
+                                                 (int16_t)u32((uint16_t)j.y_vpdu), (int16_t)u32((uint16_t)j.size_y), u32(j.avail_l) != 0, u32(j.avail_t) != 0,
+                                                 (int16_t)u32((uint16_t)j.pic_w), (int16_t)u32((uint16_t)j.pic_h), lane);
+        if (g == (src >> 4))
+            scale = s_;
+    }
     if (j.w <= 0)
-        return;                 // an empty slot of a job array the transform-block builder wrote (vvc355_itx_frame.resid_jobs)
-    const int scale = (j.joint & 16) ? (int)gld<int16_t>((const int16_t *)j.luma) : (j.joint & 8) ? lmcs_scale_from_plane<BD>(model, (const uint8_t *)j.luma, j.luma_stride / (int)sizeof(px_t), j.x_vpdu, j.y_vpdu, j.size_y,
-                                                                j.avail_l != 0, j.avail_t != 0, j.pic_w, j.pic_h, lane) : 0;
-    resid_block_add<BD>((uint8_t *)j.dst, j.dst_stride, (const int *)j.resid, j.w, j.h, j.joint, scale, lane);
+        return;                 // an empty slot of a job array the transform-block builder wrote (vvc355_itx_frame.resid_jobs), or past the end
+    if (j.joint & 16)
+        scale = (int)gld<int16_t>((const int16_t *)j.luma);
+    resid_block_add<BD, 16>((uint8_t *)j.dst, j.dst_stride, (const int *)j.resid, j.w, j.h, j.joint, scale, l16);
 }
 
 } // namespace vvc355
@@ -1316,7 +1343,7 @@ void vvc355_lmcs_vpdu_scale_pass(void *stream, int bd, const vvc355_lmcs_scale_f
 void vvc355_lmcs_chroma_resid_batch(void *stream, int bd, const vvc355_lmcs_resid_job *jobs_dev, int n_jobs, const vvc355_lmcs_model *model_dev)
 {
     if (n_jobs <= 0) return;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((vvc355::lmcs_chroma_resid_kernel<BD>), dim3((n_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs, model_dev));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((vvc355::lmcs_chroma_resid_kernel<BD>), dim3((n_jobs + 15) / 16), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs, model_dev));
     HIP_CHECK(hipGetLastError());
 }
 
