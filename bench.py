@@ -1222,8 +1222,14 @@ def build_chain(lib, torch, fr):
         # ALF (luma + chroma + CC) = every sample read once and written once, 4 B per sample at 10 bits.  The CTB kernel
         # does exactly that (the luma tile also serves CC-ALF); implementation_bytes adds its aprons (3 luma / 2 chroma samples per CTB side)
         alf_alg = (fr.width * fr.height + chroma_bytes // isz) * isz * 2
-        st_alf = Stage("alf", f"alf_ctb_kernel<{bd}, true> (+ alf_build_kernel)",
-                       lambda st: lib.vvc355_alf_frame_pass(st, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork)),
+        # the per-CTB job builder is a stage of its own, like the inter and transform job builders (it reads only the ALF tables); run once
+        # here as well, so that `--only alf` finds its jobs
+        lib.vvc355_alf_frame_build(None, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork))
+        chain.append(Stage("alf_job_build", f"alf_build_kernel<{bd}>", lambda st: lib.vvc355_alf_frame_build(st, bd, ptr(d_af), ctypes.addressof(af), ptr(d_awork)),
+                           fr.n_ctus * (ctypes.sizeof(abi.AlfCtb) + 5 * ctypes.sizeof(abi.AlfJob) + 128), writes=[d_awork]))
+        chain[-1].verify_note = "no check of its own: its descriptors are consumed by `alf`, which is checked over the whole picture"
+        st_alf = Stage("alf", f"alf_ctb_kernel<{bd}, true>",
+                       lambda st: lib.vvc355_alf_frame_filter(st, bd, ctypes.addressof(af), ptr(d_awork)),
                        alf_alg, writes=out, check=check_alf)
         st_alf.implementation_bytes = alf_alg + fr.n_ctus * ((134 * 144 - 128 * 128) + 2 * (68 * 80 - 64 * 64)) * isz
         chain.append(st_alf)
@@ -1320,7 +1326,7 @@ def verify_step(lib, torch, frame, chain, n_ctus):
         st.launch(stream)
         torch.cuda.synchronize()
         if st.check is None:
-            report[st.name] = {"checked": 0, "note": "not checked"}
+            report[st.name] = {"checked": 0, "mismatching": 0, "note": getattr(st, "verify_note", "not checked")}
             continue
         env.after = {t.data_ptr(): env.snap(t) for t in st.writes}
         t0 = time.perf_counter()

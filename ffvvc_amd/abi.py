@@ -131,6 +131,8 @@ BATCH_SIGNATURES = {
     "deblock_frame_pass": ("v", "pipp"),
     "sao_frame_pass":   ("v", "pipp"),
     "alf_frame_pass":   ("v", "pippp"),
+    "alf_frame_build":  ("v", "pippp"),
+    "alf_frame_filter": ("v", "pipp"),
     "deblock_bs_pass":  ("v", "ppp"),
     "alf_frame_work_bytes": ("z", "i"),
     "lfnst_batch":      ("v", "ppi"),

@@ -1120,19 +1120,38 @@ size_t vvc355_alf_frame_work_bytes(int n_ctbs)
     return (size_t)n_ctbs * (5 * sizeof(vvc355_alf_job) + 2 * sizeof(AlfChromaParams));
 }
 
-void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev)
+static int alf_frame_ctbs(const vvc355_alf_frame *frame_host)
 {
     const int n = frame_host->ctb_width * frame_host->ctb_height;
-    if (n <= 0) return;
-    if (frame_host->ctb_log2 < 5 || frame_host->ctb_log2 > 7 || (frame_host->width & 7) || (frame_host->height & 7)) {
+    if (n > 0 && (frame_host->ctb_log2 < 5 || frame_host->ctb_log2 > 7 || (frame_host->width & 7) || (frame_host->height & 7))) {
         fprintf(stderr, "vvc_mi355: ALF frame %dx%d (CTB log2 %d) outside the driver's domain\n", frame_host->width, frame_host->height, frame_host->ctb_log2);
         abort();
     }
+    return n;
+}
+
+void vvc355_alf_frame_build(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev)
+{
+    const int n = alf_frame_ctbs(frame_host);
+    if (n <= 0) return;
     vvc355_alf_job *luma = (vvc355_alf_job *)work_dev, *chroma = luma + n, *cc = chroma + 2 * n;
     AlfChromaParams *params = (AlfChromaParams *)(cc + 2 * n);
-    hipStream_t st = (hipStream_t)stream;
-    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((3 * n + 63) / 64), dim3(64), 0, st, frame_dev, n, luma, chroma, cc, params));
+    VVC355_BD_DISPATCH(bd, hipLaunchKernelGGL((alf_build_kernel<BD>), dim3((3 * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, frame_dev, n, luma, chroma, cc, params));
     HIP_CHECK(hipGetLastError());
+}
+
+void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev)
+{
+    vvc355_alf_frame_build(stream, bd, frame_dev, frame_host, work_dev);
+    vvc355_alf_frame_filter(stream, bd, frame_host, work_dev);
+}
+
+void vvc355_alf_frame_filter(void *stream, int bd, const vvc355_alf_frame *frame_host, const void *work_dev)
+{
+    const int n = alf_frame_ctbs(frame_host);
+    if (n <= 0) return;
+    const vvc355_alf_job *luma = (const vvc355_alf_job *)work_dev, *chroma = luma + n, *cc = chroma + 2 * n;
+    hipStream_t st = (hipStream_t)stream;
     const int ctb_size = 1 << frame_host->ctb_log2;
     if (frame_host->n_comp >= 3 && frame_host->hs == 1 && frame_host->vs == 1) {
         launch_ctb(bd, luma, chroma, cc, n, st, ctb_size);         // 4:2:0: one kernel, every plane read once and written once

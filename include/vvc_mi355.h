@@ -851,6 +851,11 @@ typedef struct vvc355_alf_frame {
 
 size_t vvc355_alf_frame_work_bytes(int n_ctbs);
 void vvc355_alf_frame_pass(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev);
+/* The two halves of the pass on their own: the descriptor builder (per-CTB jobs and parameter blocks into work_dev — it reads only the ALF
+ * tables, so it can run any time after they are on the device, like the other job builders) and the filter kernels (which read the
+ * planes).  vvc355_alf_frame_pass = build, then filter, on the same stream. */
+void vvc355_alf_frame_build(void *stream, int bd, const vvc355_alf_frame *frame_dev, const vvc355_alf_frame *frame_host, void *work_dev);
+void vvc355_alf_frame_filter(void *stream, int bd, const vvc355_alf_frame *frame_host, const void *work_dev);
 
 /* ------------------------------------------------------------------ LFNST and transform-type selection on device (itx.hip) */
 

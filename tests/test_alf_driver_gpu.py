@@ -133,7 +133,11 @@ def run_alf_frame(dev, orc, bd, fmt, mode, w, h, ctb_log2, clips):
          d_tab.ptr, d_sl.ptr, [d.ptr for d in tabs_dev])
     d_f = batch.DeviceBuffer.from_host(np.frombuffer(bytes(df), np.uint8))
     work = batch.DeviceBuffer.from_host(np.zeros(dev.vvc355_alf_frame_work_bytes(n), np.uint8))
-    dev.vvc355_alf_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df), work.ptr)
+    if (bd + len(mode) + ctb_log2) % 2:
+        dev.vvc355_alf_frame_pass(None, bd, d_f.ptr, ctypes.addressof(df), work.ptr)
+    else:                             # the two halves on their own: descriptor builder, then the filter kernels
+        dev.vvc355_alf_frame_build(None, bd, d_f.ptr, ctypes.addressof(df), work.ptr)
+        dev.vvc355_alf_frame_filter(None, bd, ctypes.addressof(df), work.ptr)
     dev.vvc355_stream_sync(None)
     for c in range(3):
         got = d_dst[c].to_host(p_src[c].dtype, p_src[c].shape)

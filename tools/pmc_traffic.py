@@ -30,7 +30,8 @@ STAGES = {                      # stage name of bench.py -> substring of the ker
     "deblock_vertical": "deblock_frame_kernel", # first deblock launch of a step
     "deblock_horizontal": "deblock_frame_kernel",   # second one
     "sao": "sao_frame_kernel",
-    "alf": "alf_",                              # the stage driver's kernels: the job builder and the CTB kernel (luma + chroma + CC-ALF)
+    "alf": "alf_ctb_kernel",                    # the CTB kernel (luma + chroma + CC-ALF)
+    "alf_job_build": "alf_build_kernel",
     "lmcs_chroma_residual_scale": "lmcs_chroma_resid_kernel",
     "lmcs_vpdu_scale_table": "lmcs_vpdu_scale_kernel",
     "side_tables_fill": "tabfill_kernel",       # both launches of a step: the side tables and the inter stage's MvField table
