@@ -1643,12 +1643,12 @@ __device__ void recon_tile_store(const uint16_t *tile, int pitch, uint8_t *plane
 }
 
 // A LIGHT CTU (vvc355_recon_ctu.flags): MARK and RESID commands only, no luma written — the chroma residuals of inter coding units that
-// chroma residual scaling keeps in the walk.  Nothing is staged: the two waves take alternate commands and add their blocks straight on the
+// chroma residual scaling keeps in the walk.  Nothing is staged: groups of sixteen lanes take the residual blocks and add them straight on the
 // planes; a block's scale comes from the luma plane (its own CTU's luma is final; a neighbour's once that neighbour's luma flag is up).
 // Inside the CTU every neighbour of a 64x64 unit belongs to an earlier unit of the same CTU (the MARKs of a conforming list say so), at
 // the CTU's edge the neighbour CTU decides (ctb_left / ctb_up), which is what ff_vvc_get_left / top_available answer for one sample.
 template <int BD>
-__device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, const vvc355_recon_ctu &ctu, const ReconCtx &cx, VVC355_GLOBAL int *state,
+__device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, ReconLds &L, const vvc355_recon_ctu &ctu, const ReconCtx &cx, VVC355_GLOBAL int *state,
                                                 const int rs, const int rx, const int ry, const int role, const int tid)
 {
     using px_t = typename Px<BD>::type;
@@ -1671,30 +1671,52 @@ __device__ __forceinline__ void recon_light_ctu(const vvc355_recon_frame &f, con
     const vvc355_recon_cmd *cmds = (const vvc355_recon_cmd *)f.cmds + ctu.first_cmd;
     const uint8_t *luma = (const uint8_t *)f.plane[0];
     const int ls = f.stride[0] / (int)sizeof(px_t);
-    int xv = -1, yv = -1, scale = 0;
-    // windows of 64 commands: lane i looks at the kind of command win + i (dword 6: mode, kind, c_idx, ref_idx), a ballot gives the
-    // residual blocks of the window, and the two waves take them alternately — only those commands are fetched whole
-    for (uint32_t win = 0; win < ctu.n_cmd; win += 64) {
-      const uint32_t kind = win + tid < ctu.n_cmd ? (gld<uint32_t>((const uint32_t *)(cmds + win + tid) + 6) >> 8) & 0xff : (uint32_t)VVC355_RECON_MARK;
-      if (__builtin_amdgcn_ballot_w64(kind != VVC355_RECON_MARK && kind != VVC355_RECON_RESID))
-          __builtin_trap();                      // a LIGHT CTU holds nothing else
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(kind == VVC355_RECON_RESID);
-      for (int turn = 0; todo; turn ^= 1) {
-        const uint32_t k = win + (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        if (turn != role)
-            continue;
-        const vvc355_recon_cmd c = load_uniform(cmds + k);
-        const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
-        if ((c.joint & 8) && (xv != (c.cu_x0 & ~(size_y - 1)) || yv != (c.cu_y0 & ~(size_y - 1)))) {
-            xv = c.cu_x0 & ~(size_y - 1); yv = c.cu_y0 & ~(size_y - 1);
+    // The scales of the CTU's 64x64 units first (at most four; the luma they average is final now), two per wave, into LDS.  Inside the CTU
+    // every neighbour of a unit belongs to an earlier unit of the same CTU, at the CTU's edge the neighbour CTU decides (ctb_left / ctb_up).
+    const int upr = ctb / size_y;                      // units per CTU row: 1 or 2
+    if (f.lmcs_model) {
+        for (int u = role; u < upr * upr; u += 2) {
+            const int xv = cx.ox + (u % upr) * size_y, yv = cx.oy + (u / upr) * size_y;
+            if (xv >= f.width || yv >= f.height)
+                continue;
             const bool avail_l = (xv & (ctb - 1)) ? true : cx.ctb_left != 0;
             const bool avail_t = (yv & (ctb - 1)) ? true : cx.ctb_up != 0;
-            scale = lmcs_scale_from_plane<BD>((const vvc355_lmcs_model *)f.lmcs_model, luma, ls, xv, yv, size_y, avail_l, avail_t, f.width, f.height, tid);
+            const int sc = lmcs_scale_from_plane<BD>((const vvc355_lmcs_model *)f.lmcs_model, luma, ls, xv, yv, size_y, avail_l, avail_t, f.width, f.height, tid);
+            L.prm[0][u] = sc;
         }
-        uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
-        resid_block_add<BD>(dst, f.stride[c_idx], (const int *)c.resid, c.w, c.h, c.joint, scale, tid);
-      }
+    }
+    __syncthreads();
+    // Then the residual blocks: they do not depend on each other, so sixteen lanes take a block and the workgroup's eight groups run eight
+    // blocks at a time.  Windows of 64 commands: lane i looks at the kind of command win + i (dword 6: mode, kind, c_idx, ref_idx), the
+    // residual blocks of the window are ranked through LDS, group g takes the blocks ranked g, g + 8, ... and fetches only those commands.
+    VVC355_LDS uint32_t *list = (VVC355_LDS uint32_t *)L.cmdbuf[role];
+    const int grp = role * 4 + (tid >> 4), l16 = tid & 15;
+    for (uint32_t win = 0; win < ctu.n_cmd; win += 64) {
+        const uint32_t kind = win + tid < ctu.n_cmd ? (gld<uint32_t>((const uint32_t *)(cmds + win + tid) + 6) >> 8) & 0xff : (uint32_t)VVC355_RECON_MARK;
+        if (__builtin_amdgcn_ballot_w64(kind != VVC355_RECON_MARK && kind != VVC355_RECON_RESID))
+            __builtin_trap();                      // a LIGHT CTU holds nothing else
+        const unsigned long long todo = __builtin_amdgcn_ballot_w64(kind == VVC355_RECON_RESID);
+        const int n_res = __builtin_popcountll(todo);
+        if (kind == VVC355_RECON_RESID)
+            list[__builtin_popcountll(todo & ((1ull << tid) - 1))] = win + (uint32_t)tid;
+        group_sync<64>();
+        for (int r = grp; r < n_res; r += 8) {
+            const uint32_t k = list[r];
+            vvc355_recon_cmd c;
+            {
+                const uint2 *p = (const uint2 *)(cmds + k);
+                uint2 q[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) q[i] = gld<uint2>(p + i);
+                __builtin_memcpy(&c, q, sizeof(c));
+            }
+            const int c_idx = c.c_idx, hs = c_idx ? f.hs : 0, vs = c_idx ? f.vs : 0;
+            const int unit = (((c.cu_y0 - cx.oy) & (ctb - 1)) / size_y) * upr + ((c.cu_x0 - cx.ox) & (ctb - 1)) / size_y;
+            const int scale = (c.joint & 8) ? L.prm[0][unit] : 0;
+            uint8_t *dst = (uint8_t *)f.plane[c_idx] + row_off(c.y0 >> vs, f.stride[c_idx]) + (c.x0 >> hs) * (int)sizeof(px_t);
+            resid_block_add<BD, 16>(dst, f.stride[c_idx], (const int *)c.resid, c.w, c.h, c.joint, scale, l16);
+        }
+        group_sync<64>();                          // the list is rewritten by the next window
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1750,7 +1772,7 @@ __device__ __forceinline__ bool recon_one_ctu(const vvc355_recon_frame &f, Recon
     }
     RTRACE(rs, 7, ticket | ((unsigned long long)blockIdx.x << 32));
     if (ctu.flags & VVC355_RECON_CTU_LIGHT) {          // workgroup-uniform
-        recon_light_ctu<BD>(f, ctu, cx, state, rs, rx, ry, role, tid);
+        recon_light_ctu<BD>(f, L, ctu, cx, state, rs, rx, ry, role, tid);
         return true;
     }
     // the three planes as the walk sees them: accessor of sample (0, 0) + stride in pixels
