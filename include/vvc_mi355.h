@@ -935,7 +935,8 @@ typedef struct vvc355_recon_cmd {
  * and upper-right neighbours that have commands, and is walked on LDS tiles by one wave per channel type).
  *   LIGHT      the CTU's commands are MARKs and RESIDs only and none touches luma: the chroma residuals of inter coding units that chroma
  *              residual scaling keeps in the walk (their scale needs the reconstructed luma of a neighbouring CTU the walk writes).  Such a
- *              CTU is not staged in LDS; its blocks are added straight on the planes, and it waits for nothing but
+ *              CTU is not staged in LDS; its blocks (disjoint, so their order does not matter: several are added at a time) go straight
+ *              on the planes, and it waits for nothing but
  *   LUMA_LEFT / LUMA_UP   the LUMA of its left / upper neighbour CTU (set when that neighbour's luma is written by the walk: the 64x64
  *              units on that edge read its last column / row, lmcs_derive_chroma_scale vvc_intra_template.c:401-410).  Ordinary CTUs
  *              publish their luma as soon as their luma commands are done, ahead of their chroma.
