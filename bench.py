@@ -1760,9 +1760,14 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; more ranks than devices (a rehearsal of the multi-rank path on a one-GPU box) share devices round-robin
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        print(f"bench.py: rank {rank}: {n_dev} device(s) for local rank {local_rank} - sharing device {local_rank % n_dev} (rehearsal, not a measurement)", file=sys.stderr)
+    local_dev = local_rank % n_dev
+    torch.cuda.set_device(local_dev)
     lib = abi.load()
-    lib.vvc355_set_device(local_rank)
+    lib.vvc355_set_device(local_dev)
 
     # ---- the frames of a step
     # GOP mode (default, --gop 16): a step decodes one hierarchical-B group of pictures of ONE stream — POC G from the previous group's
