@@ -1741,8 +1741,10 @@ def main(argv=None):
     # One HIP stream per frame in flight only helps if the streams do not share hardware queues: the runtime's default of 4 maps
     # several streams onto one in-order queue, and a frame's 2 ms intra pass then holds up the other frame behind it (measured, 8
     # frames in flight: 502 / 660 / 685 / 808 frames/s with 2 / 4 / 8 / 16 queues).  Set before the HIP runtime initialises; a
-    # value already in the environment wins.  A host that uses the C ABI with several streams needs the same setting.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, 2 * max(1, args.frames_in_flight))))
+    # value already in the environment wins.  A host that uses the C ABI with several streams needs the same setting.  Every stream counts:
+    # the GOP scheduler has 16 picture streams, two copy streams and a join stream — with 16 queues the copy streams shared queues with
+    # picture streams and the upload leg fell from 498 to 390 frames/s; with 20: 524 (and the stream without upload 575 -> 595).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(20, 2 * max(1, args.frames_in_flight) + 4)))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)         # before anything imports torch or touches HIP
     global MC_TOOLS, AFFINE_FRAC, DEBLOCK_JOBS, SAO_TABLES, ALF_TABLES, INTER_FRAC, LMCS
@@ -1806,6 +1808,8 @@ def main(argv=None):
         chains = [chains_of[(0, poc)] for poc in range(1, gop, 2)][:n_ff] or [chains_of[(0, 1)]]
         n_ff = len(frames)
         done_ev = {key: torch.cuda.Event() for key in objs}
+        copy_ev = {key: torch.cuda.Event() for key in objs}
+        copy_streams = [torch.cuda.Stream() for _ in range(2)]
         recorded = set()
         gop_ev = [torch.cuda.Event() for _ in range(n_sets)]
         join_stream = torch.cuda.Stream()
@@ -1850,10 +1854,18 @@ def main(argv=None):
         for i, (poc, lo, hi) in enumerate(order):
             ts = streams[i % len(streams)]
             if upload:
-                # what the decoder's host side sends for this picture: every per-frame table, record and descriptor array from pinned memory
-                with torch.cuda.stream(ts):
+                # what the decoder's host side sends for this picture: every per-frame table, record and descriptor array from pinned memory.
+                # The copies do not depend on the reference pictures, so they go out on a copy stream as soon as the picture object is free
+                # (its previous use, three groups back, is done) and the picture's own stream only waits for their event: a decoder that has
+                # parsed ahead uploads ahead.
+                cs = copy_streams[i % len(copy_streams)]
+                if (j, poc) in recorded:
+                    cs.wait_event(done_ev[(j, poc)])
+                with torch.cuda.stream(cs):
                     for dst_t, src_t in pinned_of[(j, poc)]:
                         dst_t.copy_(src_t, non_blocking=True)
+                copy_ev[(j, poc)].record(cs)
+                ts.wait_event(copy_ev[(j, poc)])
             for dep in {((j - 1) % n_sets, gop) if q == 0 else (j, q) for q in (lo, hi)}:
                 if dep in recorded:
                     ts.wait_event(done_ev[dep])
@@ -2018,10 +2030,21 @@ def main(argv=None):
             run_gop(k0 + k, upload=True)
         torch.cuda.synchronize()
         el_up = sharding.max_over_ranks(dist, torch, world, time.perf_counter() - t1, "cpu")
+        # what the link gives for the same kind of copy alone (one picture's arena, pinned host -> device, back to back): the upload leg's ceiling
+        a_dst, a_src = pinned_of[(0, 1)][0]
+        for _ in range(2):
+            a_dst.copy_(a_src, non_blocking=True)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for _ in range(16):
+            a_dst.copy_(a_src, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbps = 16 * a_src.numel() * a_src.element_size() / (time.perf_counter() - t_h) / 1e9
         upload = {"value": world * gop * args.steps / el_up, "unit": "frames/s", "descriptor_bytes_per_frame": int(up_bytes),
+                  "copy_GBps_in_this_leg": world * gop * args.steps * up_bytes / el_up / 1e9 / world, "measured_pinned_h2d_GBps": h2d_gbps,
                   "ms_per_step": el_up / args.steps * 1e3, "frames_per_step": gop,
                   "what": "the same groups of pictures with every picture's per-frame tables, records and descriptor arrays copied from pinned host memory "
-                          "on the picture's stream first (the decoder's host side hands them over per picture)",
+                          "first — on a copy stream, as soon as the picture object is free; the picture's own stream waits for the copy's event",
                   "not_included": "coefficient levels (int32 in the reference ABI, generated on the device here)"}
     elif args.with_upload and not args.graph:
         pinned = [[(frames[f].torch_of[p_], torch.from_numpy(h_).pin_memory()) for p_, h_ in frames[f].host.items()] for f in range(n_ff)]

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16     # what bench.py sets for itself; exported here because the profiler starts the runtime first
+export GPU_MAX_HW_QUEUES=20     # what bench.py sets for itself; exported here because the profiler starts the runtime first
 B="python3 $R/bench.py --no-cpu-baseline --no-verify"
 F1="--gop 0 --frames-in-flight 1"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o run -- $B --steps 10 --warmup 2 --no-upload > $O/trace_default.log 2>&1

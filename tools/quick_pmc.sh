@@ -5,8 +5,8 @@ tag=$1; only=$2; shift 2
 O=$R/gpurun_out/pmc_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16
-B="python3 $R/bench.py --no-cpu-baseline --no-verify --steps 2 --warmup 1 --frames-in-flight 1 --only $only $@"
+export GPU_MAX_HW_QUEUES=20
+B="python3 $R/bench.py --no-cpu-baseline --no-verify --steps 2 --warmup 1 --gop 0 --frames-in-flight 1 --only $only $@"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --output-format csv -d $O/sq -o run -- $B > $O/sq.log 2>&1 || echo sq failed
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -o run -- $B > $O/sq2.log 2>&1 || echo sq2 failed
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o run -- $B > $O/fetch.log 2>&1 || echo fetch failed

@@ -5,7 +5,7 @@ tag=$1; shift
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=20
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o run -- python3 $R/bench.py --no-cpu-baseline --no-verify --steps 20 --warmup 3 "$@" > $O/bench.log 2>&1
 find $O -name "*kernel_trace.csv" -size +4M -delete
 f=$(find $O -name "*kernel_stats.csv" | head -1)
