@@ -44,6 +44,8 @@ DEBLOCK_JOBS = False           # deblocking through the stage driver (edge param
 AFFINE_FRAC = 0.06             # fraction of the inter CTUs predicted as affine (4x4 sub-blocks + PROF on both lists); --affine-frac
 GPM_FRAC = 0.05                # fraction of the regular inter blocks coded as geometric partitions (two uni-predictions + mask blend)
 CIIP_FRAC = 0.02               # fraction of the CTUs whose coding units are combined inter / intra (inter prediction aside, planar intra + blend in RECON)
+# stages of a picture that read nothing a reference picture writes (bench.py GOP scheduler: launched ahead of the reference waits)
+REF_FREE_STAGES = {"inter_mvf_fill", "inter_job_build", "itx_job_build", "intra_tb_dequant_lfnst_itx", "side_tables_fill", "deblock_bs", "alf_job_build"}
 RECON_FRAMES = []              # the host copies of every picture's vvc355_recon_frame (the launch reads its grid hint from them)
 LMCS = True                    # sh_lmcs_used_flag + ph_chroma_residual_scale_flag on: forward luma map on the inter prediction, chroma residual scaling (--no-lmcs)
 MC_TOOLS = 3                   # bit 0: DMVR, bit 1: BDOF on the bi-predicted blocks (profiling aid --mc-tools; the metric uses 3)
@@ -1866,17 +1868,25 @@ def main(argv=None):
                         dst_t.copy_(src_t, non_blocking=True)
                 copy_ev[(j, poc)].record(cs)
                 ts.wait_event(copy_ev[(j, poc)])
+            if k >= 2:
+                ts.wait_event(gop_ev[(k - 2) % n_sets])            # nothing reads this set's pictures any more
+            timed_picture = (j, poc) == (0, 1) and events is not None          # the frame whose dominant stage carries the events
+            sh = ts.cuda_stream
+            if not timed_picture:
+                # the stages that read only what the parser produced (table fills, job builders, the intra blocks' transforms, boundary
+                # strengths) do not depend on the reference pictures: they go out before the picture waits for them
+                for st in chains_of[(j, poc)]:
+                    if st.name in REF_FREE_STAGES:
+                        st.launch(sh)
             for dep in {((j - 1) % n_sets, gop) if q == 0 else (j, q) for q in (lo, hi)}:
                 if dep in recorded:
                     ts.wait_event(done_ev[dep])
-            if k >= 2:
-                ts.wait_event(gop_ev[(k - 2) % n_sets])            # nothing reads this set's pictures any more
-            if (j, poc) == (0, 1) and events is not None:           # the frame whose dominant stage carries the events
+            if timed_picture:
                 run_frame(0, events, step, only, stream=ts)
             else:
-                sh = ts.cuda_stream
                 for st in chains_of[(j, poc)]:
-                    st.launch(sh)
+                    if st.name not in REF_FREE_STAGES:
+                        st.launch(sh)
             done_ev[(j, poc)].record(ts)
             recorded.add((j, poc))
         for (poc, _lo, _hi) in order:
