@@ -21,20 +21,28 @@ namespace vvc355 {
 static constexpr int kMaxUnits = 32 * 32;          // 128x128 CTU in 4x4 units
 static constexpr uint16_t kNoRec = 0xffff;
 
-// records [first, last) of one kind -> map[unit within the CTU] = record index - first
+// records [first, last) of one kind -> map[unit within the CTU] = record index - first.  `map_tree1` != 0: the records carry a tree bit
+// (flags bit 7) and those of tree 1 go to that map.  Sixteen lanes per record; widths are powers of two in every partitioning a decoder
+// produces (the general case keeps the division).
 template <typename REC>
-__device__ __forceinline__ void map_records(uint16_t *map, const REC *recs, int first, int last, int ox, int oy, int lw, int tree_filter)
+__device__ __forceinline__ void map_records(uint16_t *map, uint16_t *map_tree1, const REC *recs, int first, int last, int ox, int oy, int lw)
 {
     const int sub = threadIdx.x & 15;
     for (int r = first + (threadIdx.x >> 4); r < last; r += 16) {
         const uint2 head = gld<uint2>(recs + r);               // x0 y0 | w h flags pad: the same 8 bytes for all three record kinds
         const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff, flags = (head.y >> 16) & 0xff;
-        if (tree_filter >= 0 && (flags >> 7) != tree_filter)
-            continue;
+        uint16_t *m = (map_tree1 && (flags >> 7)) ? map_tree1 : map;
         const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
-        for (int i = sub; i < n; i += 16) {
-            const int dy = i / uw, dx = i - dy * uw;
-            map[((uy + dy) << lw) + ux + dx] = (uint16_t)(r - first);
+        const int base = (uy << lw) + ux;
+        if ((uw & (uw - 1)) == 0) {
+            const int lg = __builtin_ctz(uw | 64);
+            for (int i = sub; i < n; i += 16)
+                m[base + ((i >> lg) << lw) + (i & (uw - 1))] = (uint16_t)(r - first);
+        } else {
+            for (int i = sub; i < n; i += 16) {
+                const int dy = i / uw, dx = i - dy * uw;
+                m[base + (dy << lw) + dx] = (uint16_t)(r - first);
+            }
         }
     }
 }
@@ -56,22 +64,9 @@ __global__ __launch_bounds__(256) void tabfill_kernel(const vvc355_tab_fill *__r
     const vvc355_cu_rec *cus = (const vvc355_cu_rec *)f.cu;
     const vvc355_tu_rec *tus = (const vvc355_tu_rec *)f.tu;
     const vvc355_mv_rec *mvs = (const vvc355_mv_rec *)f.mv;
-    map_records(map[0], cus, cu0, cu1, ox, oy, lw, -1);
-    map_records(map[1], tus, tu0, tu1, ox, oy, lw, 0);
-    map_records(map[2], tus, tu0, tu1, ox, oy, lw, 1);
-    // (motion records are 32 bytes: the head is their first 8)
-    {
-        const int sub = threadIdx.x & 15;
-        for (int r = mv0 + (threadIdx.x >> 4); r < mv1; r += 16) {
-            const uint2 head = gld<uint2>(mvs + r);
-            const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff;
-            const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
-            for (int i = sub; i < n; i += 16) {
-                const int dy = i / uw, dx = i - dy * uw;
-                map[3][((uy + dy) << lw) + ux + dx] = (uint16_t)(r - mv0);
-            }
-        }
-    }
+    map_records(map[0], (uint16_t *)nullptr, cus, cu0, cu1, ox, oy, lw);
+    map_records(map[1], map[2], tus, tu0, tu1, ox, oy, lw);
+    map_records(map[3], (uint16_t *)nullptr, mvs, mv0, mv1, ox, oy, lw);          // (motion records are 32 bytes: the head is their first 8)
     __syncthreads();
     const int pw = f.width >> 2, ph = f.height >> 2;                // picture size in units
     for (int i = threadIdx.x; i < n_units; i += 256) {
