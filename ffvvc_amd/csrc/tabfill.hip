@@ -25,23 +25,33 @@ static constexpr uint16_t kNoRec = 0xffff;
 // (flags bit 7) and those of tree 1 go to that map.  Sixteen lanes per record; widths are powers of two in every partitioning a decoder
 // produces (the general case keeps the division).
 template <typename REC>
-__device__ __forceinline__ void map_records(uint16_t *map, uint16_t *map_tree1, const REC *recs, int first, int last, int ox, int oy, int lw)
+__device__ __forceinline__ void map_records(uint16_t *map, uint16_t *map_tree1, uint2 *heads, const REC *recs, int first, int last, int ox, int oy, int lw)
 {
     const int sub = threadIdx.x & 15;
-    for (int r = first + (threadIdx.x >> 4); r < last; r += 16) {
-        const uint2 head = gld<uint2>(recs + r);               // x0 y0 | w h flags pad: the same 8 bytes for all three record kinds
-        const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff, flags = (head.y >> 16) & 0xff;
-        uint16_t *m = (map_tree1 && (flags >> 7)) ? map_tree1 : map;
-        const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
-        const int base = (uy << lw) + ux;
-        if ((uw & (uw - 1)) == 0) {
-            const int lg = __builtin_ctz(uw | 64);
-            for (int i = sub; i < n; i += 16)
-                m[base + ((i >> lg) << lw) + (i & (uw - 1))] = (uint16_t)(r - first);
-        } else {
-            for (int i = sub; i < n; i += 16) {
-                const int dy = i / uw, dx = i - dy * uw;
-                m[base + (dy << lw) + dx] = (uint16_t)(r - first);
+    // the records' heads (x0 y0 | w h flags pad: the same 8 bytes for all three record kinds) come in through LDS, 1024 at a time with one
+    // coalesced round trip, so that the painting passes below (sixteen records per pass) do not each wait for a global load
+    for (int c0 = first; c0 < last; c0 += kMaxUnits) {
+        const int nc = min(kMaxUnits, last - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc; i += 256)
+            heads[i] = gld<uint2>(recs + c0 + i);
+        __syncthreads();
+        for (int k = threadIdx.x >> 4; k < nc; k += 16) {
+            const uint2 head = heads[k];
+            const int r = c0 + k;
+            const int x0 = (int16_t)(head.x & 0xffff), y0 = (int16_t)(head.x >> 16), w = head.y & 0xff, h = (head.y >> 8) & 0xff, flags = (head.y >> 16) & 0xff;
+            uint16_t *m = (map_tree1 && (flags >> 7)) ? map_tree1 : map;
+            const int ux = (x0 - ox) >> 2, uy = (y0 - oy) >> 2, uw = w >> 2, n = uw * (h >> 2);
+            const int base = (uy << lw) + ux;
+            if ((uw & (uw - 1)) == 0) {
+                const int lg = __builtin_ctz(uw | 64);
+                for (int i = sub; i < n; i += 16)
+                    m[base + ((i >> lg) << lw) + (i & (uw - 1))] = (uint16_t)(r - first);
+            } else {
+                for (int i = sub; i < n; i += 16) {
+                    const int dy = i / uw, dx = i - dy * uw;
+                    m[base + (dy << lw) + dx] = (uint16_t)(r - first);
+                }
             }
         }
     }
@@ -50,6 +60,7 @@ __device__ __forceinline__ void map_records(uint16_t *map, uint16_t *map_tree1, 
 __global__ __launch_bounds__(256) void tabfill_kernel(const vvc355_tab_fill *__restrict__ fp)
 {
     __shared__ uint16_t map[4][kMaxUnits];             // coding unit, transform unit tree 0, tree 1, motion
+    __shared__ uint2 heads[kMaxUnits];
     const vvc355_tab_fill f = load_uniform(fp);
     const int rs = blockIdx.x, ry = rs / f.ctb_width, rx = rs - ry * f.ctb_width;
     const int lw = f.ctb_log2 - 2, side = 1 << lw, n_units = side * side;
@@ -64,9 +75,9 @@ __global__ __launch_bounds__(256) void tabfill_kernel(const vvc355_tab_fill *__r
     const vvc355_cu_rec *cus = (const vvc355_cu_rec *)f.cu;
     const vvc355_tu_rec *tus = (const vvc355_tu_rec *)f.tu;
     const vvc355_mv_rec *mvs = (const vvc355_mv_rec *)f.mv;
-    map_records(map[0], (uint16_t *)nullptr, cus, cu0, cu1, ox, oy, lw);
-    map_records(map[1], map[2], tus, tu0, tu1, ox, oy, lw);
-    map_records(map[3], (uint16_t *)nullptr, mvs, mv0, mv1, ox, oy, lw);          // (motion records are 32 bytes: the head is their first 8)
+    map_records(map[0], (uint16_t *)nullptr, heads, cus, cu0, cu1, ox, oy, lw);
+    map_records(map[1], map[2], heads, tus, tu0, tu1, ox, oy, lw);
+    map_records(map[3], (uint16_t *)nullptr, heads, mvs, mv0, mv1, ox, oy, lw);          // (motion records are 32 bytes: the head is their first 8)
     __syncthreads();
     const int pw = f.width >> 2, ph = f.height >> 2;                // picture size in units
     for (int i = threadIdx.x; i < n_units; i += 256) {
